@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports rendeirolab/stainx v0.1.4 from /root/reference/src, runs its
+``backend="torch"`` CPU path on seeded inputs produced by this repository's own
+generator (``stainx_amd/synth.py``), and stores inputs (when small), outputs
+and intermediates as ``.npz`` arrays.  Only data is written -- no reference
+source.  Intermediates are captured by wrapping the reference's helper
+functions (cov / eigh / percentile / lstsq) at run time.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, "/root/reference/src")
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+
+import stainx  # noqa: E402  (the reference)
+from stainx.backends.torch_backend import MacenkoTorch  # noqa: E402
+
+from stainx_amd import synth  # noqa: E402
+
+assert stainx.__version__ == "0.1.4", stainx.__version__
+torch.manual_seed(0)
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
+def to_np(t: torch.Tensor) -> np.ndarray:
+    """bf16 has no numpy dtype: store its bit pattern as uint16."""
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16)
+    return t.numpy()
+
+
+class Capture:
+    """Logs the per-tile intermediates of MacenkoTorch by wrapping its static helpers."""
+
+    def __init__(self):
+        self.rows = []
+        self._cur = None
+        self._orig = {}
+
+    def __enter__(self):
+        for name in ("_cov_torch", "_eigh_torch", "_percentile_torch", "_lstsq_torch"):
+            self._orig[name] = getattr(MacenkoTorch, name)
+
+        def cov(x):
+            out = self._orig["_cov_torch"](x)
+            self._cur = {"n_kept": int(x.shape[0]), "cov": out.clone().numpy(), "pct": []}
+            self.rows.append(self._cur)
+            return out
+
+        def eigh(c):
+            vals, vecs = self._orig["_eigh_torch"](c)
+            self._cur["eigvals"] = vals.clone().numpy()
+            self._cur["vecs"] = vecs[:, [1, 2]].clone().numpy()
+            return vals, vecs
+
+        def pct(t, q):
+            v = self._orig["_percentile_torch"](t, q)
+            self._cur["pct"].append(np.float32(v))
+            return v
+
+        def lstsq(a, b):
+            self._cur["he"] = a.clone().numpy()
+            return self._orig["_lstsq_torch"](a, b)
+
+        MacenkoTorch._cov_torch = staticmethod(cov)
+        MacenkoTorch._eigh_torch = staticmethod(eigh)
+        MacenkoTorch._percentile_torch = staticmethod(pct)
+        MacenkoTorch._lstsq_torch = staticmethod(lstsq)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(MacenkoTorch, name, staticmethod(fn))
+
+    def stacked(self) -> dict:
+        return {
+            "n_kept": np.array([r["n_kept"] for r in self.rows], dtype=np.int64),
+            "cov": np.stack([r["cov"] for r in self.rows]),
+            "eigvals": np.stack([r["eigvals"] for r in self.rows]),
+            "vecs": np.stack([r["vecs"] for r in self.rows]),
+            "phi_lo": np.array([r["pct"][0] for r in self.rows], dtype=np.float32),
+            "phi_hi": np.array([r["pct"][1] for r in self.rows], dtype=np.float32),
+            "he": np.stack([r["he"] for r in self.rows]),
+            "max_c": np.stack([np.array(r["pct"][2:4], dtype=np.float32) for r in self.rows]),
+        }
+
+
+def fit_reference(hw):
+    ref = synth.reference_tile(*hw)
+    m = stainx.Macenko(device="cpu", backend="torch")
+    m.fit(ref)
+    return ref, m._stain_matrix.clone(), m._target_max_conc.clone()
+
+
+def g1_macenko_small():
+    """Full outputs on small Beer-Lambert tiles for every input dtype."""
+    for hw in ((64, 64), (128, 128), (321, 199)):
+        ref, sm, tmc = fit_reference(hw)
+        small = hw == (64, 64)
+        src = synth.he_batch(3 if small else 2, *hw, seed0=123, scale_step=0.075)   # scales 1.0, 1.075, (1.15)
+        blob = {"ref_u8": to_np(ref), "src_u8": to_np(src), "stain_matrix": to_np(sm), "target_max_conc": to_np(tmc)}
+        for name, dt in (("f32", torch.float32), ("u8", torch.uint8), ("bf16", torch.bfloat16), ("f16", torch.float16), ("f64", torch.float64)):
+            if name == "f64" and not small:
+                continue
+            x = synth.as_dtype(src, dt)
+            m = stainx.Macenko(device="cpu", backend="torch")
+            m._stain_matrix, m._target_max_conc, m._is_fitted = sm, tmc, True
+            with Capture() as cap:
+                out = m.transform(x)
+            assert out.dtype == dt
+            blob[f"out_{name}"] = to_np(out)
+            if small or name in ("f32", "bf16"):
+                m.normalize_to_0_1 = True
+                blob[f"out01_{name}"] = to_np(m.transform(x))
+            if name in ("f32", "u8"):
+                for k, v in cap.stacked().items():
+                    blob[f"{name}_{k}"] = v
+        np.savez_compressed(HERE / f"g1_macenko_{hw[0]}x{hw[1]}.npz", **blob)
+        print("g1", hw, "done")
+
+
+def g2_macenko_config2():
+    """BASELINE config 2 (64x3x512x512 fp32): per-tile intermediates + a 4096-pixel strided output subsample per tile."""
+    hw = (512, 512)
+    ref, sm, tmc = fit_reference(hw)
+    src = synth.he_batch(64, *hw)
+    x = synth.as_dtype(src, torch.float32)
+    m = stainx.Macenko(device="cpu", backend="torch")
+    m._stain_matrix, m._target_max_conc, m._is_fitted = sm, tmc, True
+    with Capture() as cap:
+        out = m.transform(x)
+    stride = (hw[0] * hw[1]) // 4096
+    sub = out.reshape(64, 3, -1)[:, :, ::stride].contiguous()
+    blob = {"src_sha256": np.array(sha(src)), "ref_sha256": np.array(sha(ref)), "stain_matrix": to_np(sm),
+            "target_max_conc": to_np(tmc), "sub_stride": np.array(stride), "out_sub": to_np(sub),
+            "out_mean": to_np(out.double().mean(dim=(1, 2, 3)))}
+    blob.update(cap.stacked())
+    np.savez_compressed(HERE / "g2_macenko_config2.npz", **blob)
+    print("g2 done")
+
+
+def g3_macenko_fit():
+    blob = {}
+    for tag, hw, n in (("single64", (64, 64), 1), ("single224", (224, 224), 1), ("pooled4x224", (224, 224), 4), ("pooled8x128", (128, 128), 8)):
+        tiles = synth.reference_tile(*hw) if n == 1 else synth.he_batch(n, *hw)
+        m = stainx.Macenko(device="cpu", backend="torch")
+        with Capture() as cap:
+            m.fit(tiles)
+        blob[f"{tag}_u8"] = to_np(tiles)
+        blob[f"{tag}_he"] = to_np(m._stain_matrix)
+        blob[f"{tag}_max_c"] = to_np(m._target_max_conc)
+        blob[f"{tag}_n_kept"] = cap.stacked()["n_kept"]
+        mf = stainx.Macenko(device="cpu", backend="torch")
+        mf.fit(synth.as_dtype(tiles, torch.float32))
+        blob[f"{tag}_he_f32in"] = to_np(mf._stain_matrix)
+        blob[f"{tag}_max_c_f32in"] = to_np(mf._target_max_conc)
+    np.savez_compressed(HERE / "g3_macenko_fit.npz", **blob)
+    print("g3 done")
+
+
+def g4_reinhard():
+    blob = {}
+    for tag, hw, n in (("cfg1_512", (512, 512), 1), ("b2_128", (128, 128), 2), ("odd_67x45", (67, 45), 3)):
+        ref = synth.noise_u8((1, 3, *hw), 42)
+        src = synth.noise_u8((n, 3, *hw), 43)
+        for name, dt in (("f32", torch.float32), ("u8", torch.uint8), ("bf16", torch.bfloat16)):
+            r = stainx.Reinhard(device="cpu", backend="torch")
+            r.fit(synth.as_dtype(ref, dt))
+            out = r.transform(synth.as_dtype(src, dt))
+            assert out.dtype == dt
+            blob[f"{tag}_{name}_ref_mean"] = to_np(r._reference_mean)
+            blob[f"{tag}_{name}_ref_std"] = to_np(r._reference_std)
+            if hw[0] * hw[1] > 128 * 128:
+                blob[f"{tag}_{name}_out_sub"] = to_np(out.reshape(n, 3, -1)[:, :, ::61].contiguous())
+            else:
+                blob[f"{tag}_{name}_out"] = to_np(out)
+    # Beer-Lambert tiles too (smooth data, fit on one tile, transform a batch).
+    ref = synth.reference_tile(96, 96)
+    src = synth.he_batch(2, 96, 96, seed0=500, scale_step=0.1)
+    r = stainx.Reinhard(device="cpu", backend="torch")
+    r.fit(ref)
+    blob["he96_ref_mean"], blob["he96_ref_std"] = to_np(r._reference_mean), to_np(r._reference_std)
+    blob["he96_out_u8"] = to_np(r.transform(src))
+    blob["he96_out_f32"] = to_np(r.transform(synth.as_dtype(src, torch.float32)))
+    np.savez_compressed(HERE / "g4_reinhard.npz", **blob)
+    print("g4 done")
+
+
+def g5_histogram_matching():
+    from stainx.backends.torch_backend import HistogramMatchingTorch
+
+    blob = {}
+    ref = synth.noise_u8((1, 3, 128, 128), 42)
+    src = synth.noise_u8((2, 3, 128, 128), 43)
+    he_ref = synth.reference_tile(128, 128)
+    he_src = synth.he_batch(2, 128, 128, seed0=700, scale_step=0.1)
+    for tag, r8, s8 in (("noise", ref, src), ("he", he_ref, he_src)):
+        blob[f"{tag}_ref_u8"], blob[f"{tag}_src_u8"] = to_np(r8), to_np(s8)
+        for name, dt in (("u8", torch.uint8), ("f32", torch.float32), ("bf16", torch.bfloat16)):
+            for axis in (1, -1):
+                rin, sin = synth.as_dtype(r8, dt), synth.as_dtype(s8, dt)
+                if axis == -1:
+                    rin, sin = rin.permute(0, 2, 3, 1).contiguous(), sin.permute(0, 2, 3, 1).contiguous()
+                h = stainx.HistogramMatching(device="cpu", backend="torch", channel_axis=axis)
+                h.fit(rin)
+                out = h.transform(sin)
+                key = f"{tag}_{name}_{'nchw' if axis == 1 else 'nhwc'}"
+                blob[f"{key}_out"] = to_np(out)
+                blob[f"{key}_ref_hists"] = np.stack([to_np(x) for x in h._ref_histograms_256])
+        # integer histograms + float LUT of the uint8 NCHW case, recomputed with the reference's own torch ops
+        be = HistogramMatchingTorch("cpu", channel_axis=1)
+        h = stainx.HistogramMatching(device="cpu", backend="torch")
+        h.fit(r8)
+        counts, luts = [], []
+        for c in range(3):
+            flat = s8[:, c].reshape(-1)
+            cnt = torch.bincount(flat.long(), minlength=256)
+            counts.append(cnt.numpy())
+            # The LUT is not exposed by the public API: read it through the output of the real transform at
+            # each grey level present in the source (-1 marks absent levels).
+            out_c = be.transform(s8, h._ref_histograms_256)[:, c].reshape(-1)
+            lut = torch.full((256,), -1.0)
+            lut[flat.long()] = out_c.float()
+            luts.append(lut.numpy())
+        blob[f"{tag}_counts"] = np.stack(counts)
+        blob[f"{tag}_lut_u8_trunc"] = np.stack(luts)
+    np.savez_compressed(HERE / "g5_histogram_matching.npz", **blob)
+    print("g5 done")
+
+
+def g6_edge_cases():
+    blob = {}
+    ref, sm, tmc = fit_reference((64, 64))
+    blob["stain_matrix"], blob["target_max_conc"] = to_np(sm), to_np(tmc)
+    # (a) near-white tile: fewer than 3 pixels pass the OD filter -> all-pixel fallback (torch_backend.py:409-410)
+    gen = torch.Generator().manual_seed(9)
+    white = (236 + (torch.rand(1, 3, 48, 48, generator=gen) * 19)).floor().clamp(0, 255).to(torch.uint8)
+    two = white.clone()
+    two[0, :, 5, 7] = torch.tensor([60, 40, 90], dtype=torch.uint8)
+    two[0, :, 20, 3] = torch.tensor([80, 50, 120], dtype=torch.uint8)
+    # (b) float input pushed above 1 (ColorJitter) is NOT rescaled (torch_backend.py:104-113)
+    jitter = synth.as_dtype(synth.he_batch(1, 64, 64, seed0=77), torch.float32) * 1.2
+    # (c) a tile with many exactly tied pixels (flat blocks)
+    flat = synth.he_batch(1, 64, 64, seed0=31)
+    flat = flat[:, :, ::8, ::8].repeat_interleave(8, dim=2).repeat_interleave(8, dim=3).contiguous()
+    for tag, x in (("white", white), ("white2", two), ("jitter", jitter), ("flat", flat)):
+        m = stainx.Macenko(device="cpu", backend="torch")
+        m._stain_matrix, m._target_max_conc, m._is_fitted = sm, tmc, True
+        with Capture() as cap:
+            out = m.transform(x)
+        blob[f"{tag}_in"] = to_np(x)
+        blob[f"{tag}_out"] = to_np(out)
+        for k, v in cap.stacked().items():
+            blob[f"{tag}_{k}"] = v
+    np.savez_compressed(HERE / "g6_edge_cases.npz", **blob)
+    print("g6 done")
+
+
+def g8_transform_module():
+    """StainNormalizerTransform (config 5 shape family, small): bf16 reference-mode and batch-mode outputs."""
+    blob = {}
+    ref = synth.reference_tile(56, 56)
+    src = synth.he_batch(4, 56, 56, seed0=300, scale_step=0.03)
+    for name, dt in (("bf16", torch.bfloat16), ("f32", torch.float32), ("u8", torch.uint8)):
+        t = stainx.StainNormalizerTransform(method="macenko", mode="reference", reference=synth.as_dtype(ref, dt), device="cpu", backend="torch")
+        blob[f"reference_{name}"] = to_np(t(synth.as_dtype(src, dt)))
+        tb = stainx.StainNormalizerTransform(method="macenko", mode="batch", device="cpu", backend="torch", batch_ref_index=1)
+        blob[f"batch_{name}"] = to_np(tb(synth.as_dtype(src, dt)))
+    blob["ref_u8"], blob["src_u8"] = to_np(ref), to_np(src)
+    np.savez_compressed(HERE / "g8_transform_module.npz", **blob)
+    print("g8 done")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8"]
+    table = {"g1": g1_macenko_small, "g2": g2_macenko_config2, "g3": g3_macenko_fit, "g4": g4_reinhard,
+             "g5": g5_histogram_matching, "g6": g6_edge_cases, "g8": g8_transform_module}
+    for w in which:
+        table[w]()
