@@ -1,0 +1,110 @@
+"""ctypes binding of ``libstainx_hip.so`` (C ABI declared in ``include/stainx_hip.h``).
+
+The library is the product: nothing here falls back to torch ops or to the CPU.  If the shared
+object is missing or does not match the header's ABI version, ``HIP_AVAILABLE`` is False and
+:func:`require` raises ``ImportError`` -- the analogue of ``stainx_cuda_torch.FUNCTIONS_AVAILABLE``
+(reference src/stainx_cuda_torch/__init__.py:31-49).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import torch
+
+ABI_VERSION = 1
+LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libstainx_hip.so"
+
+SX_OK, SX_ERR_BAD_ARG, SX_ERR_DTYPE, SX_ERR_WORKSPACE, SX_ERR_LAUNCH = range(5)
+MACENKO_NORMALIZE_0_1 = 1
+MACENKO_PARAM_FLOATS = 48
+
+DTYPE_CODES = {torch.uint8: 0, torch.float16: 1, torch.bfloat16: 2, torch.float32: 3, torch.float64: 4}
+
+_c = ctypes
+_vp, _i64, _int, _uint, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_uint, _c.c_size_t
+
+# name -> (restype, argtypes); every symbol include/stainx_hip.h declares
+SIGNATURES = {
+    "sx_version": (_int, []),
+    "sx_last_error_string": (_c.c_char_p, []),
+    "sx_macenko_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "sx_macenko_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _uint, _vp, _sz, _vp]),
+    "sx_macenko_fit": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "sx_macenko_tile_params": (_int, [_vp, _i64, _vp, _vp]),
+    "sx_reinhard_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "sx_reinhard_fit": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "sx_reinhard_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "sx_hm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "sx_hm_fit": (_int, [_vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
+    "sx_hm_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+_load_error: str | None = None
+
+
+def _load():
+    global _lib, _load_error
+    if _lib is not None or _load_error is not None:
+        return _lib
+    path = Path(os.environ.get("STAINX_HIP_LIB", LIB_PATH))
+    try:
+        lib = ctypes.CDLL(str(path))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        got = lib.sx_version()
+        if got != ABI_VERSION:
+            raise OSError(f"ABI version {got} != expected {ABI_VERSION}")
+        _lib = lib
+    except (OSError, AttributeError) as exc:
+        _load_error = f"{path}: {exc}"
+    return _lib
+
+
+def library_available() -> bool:
+    """The shared object loads and exports every declared symbol (no GPU needed)."""
+    return _load() is not None
+
+
+def hip_available() -> bool:
+    """Library loaded AND a ROCm device is visible to torch."""
+    return library_available() and torch.version.hip is not None and torch.cuda.is_available()
+
+
+def require():
+    lib = _load()
+    if lib is None:
+        raise ImportError(f"libstainx_hip.so is not built or not loadable ({_load_error}). Build it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                          "There is no CPU fallback in this package.")
+    return lib
+
+
+def last_error() -> str:
+    return require().sx_last_error_string().decode("utf-8", "replace")
+
+
+def check(code: int, what: str) -> None:
+    if code == SX_OK:
+        return
+    msg = f"{what} failed (status {code}): {last_error()}"
+    raise RuntimeError(msg)      # the reference's TORCH_CHECK failures surface as RuntimeError too
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Scratch:
+    """Grow-only device workspace owned by torch's caching allocator (the library never allocates)."""
+
+    def __init__(self):
+        self._buf: torch.Tensor | None = None
+
+    def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
+        if self._buf is None or self._buf.device != device or self._buf.numel() < nbytes:
+            self._buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self._buf

@@ -1,0 +1,246 @@
+"""``backend="torch_hip"``: torch.Tensor in, torch.Tensor out, arithmetic in libstainx_hip.so.
+
+Same class contract as the reference's plugin surface (src/stainx/backends/torch_cuda_backend.py):
+``cls(device, **kwargs)`` then ``impl.transform(images, *reference_params)``; exceptions keep the
+reference's types (``ImportError`` when the native library is missing, ``ValueError`` for a non-GPU
+device or bad shapes, ``RuntimeError`` from the native layer).  Unlike the reference, fit-time
+statistics are computed on the device by the same library (reference: always torch on CPU,
+torch_backend.py:463-466) -- there is no torch-op or CPU path in this package.
+"""
+from __future__ import annotations
+
+import torch
+
+from stainx_amd import _native
+
+HIP_AVAILABLE = _native.library_available()
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _native.DTYPE_CODES[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported image dtype {t.dtype}; supported: {sorted(str(d) for d in _native.DTYPE_CODES)}") from None
+
+
+class TorchHIPBackendBase:
+    """Common device checks (mirrors TorchCUDABackendBase, torch_cuda_backend.py:17-33)."""
+
+    def __init__(self, device: str | torch.device | None = None):
+        if not _native.library_available():
+            _native.require()                      # raises ImportError with the build hint
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("no ROCm device is available on this system")
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError(f"HIP backend requires a CUDA (ROCm) device, got {self.device.type}")
+        if self.device.index is None and torch.cuda.is_available():
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._lib = _native.require()
+        self._scratch = _native.Scratch()
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+
+class MacenkoHIP(TorchHIPBackendBase):
+    """Macenko transform / fit on the GPU (numerics of MacenkoTorch, torch_backend.py:358-560)."""
+
+    def __init__(self, device: str | torch.device | None = None, precision: str = "stable"):
+        super().__init__(device)
+        if precision not in ("stable", "fast"):
+            raise ValueError(f"precision must be 'stable' or 'fast', got {precision!r}")
+        # One numerical path: fp64 covariance + fp32 pixels.  "fast" is accepted for API parity
+        # (torch_cuda_backend.py:114-118) and currently selects the same kernels.
+        self._precision = precision
+        self.last_workspace: torch.Tensor | None = None
+
+    @staticmethod
+    def _check_images(images: torch.Tensor, what: str) -> None:
+        if images.dim() != 4:
+            raise ValueError(f"Macenko expects NCHW images, got shape {tuple(images.shape)}")
+        if images.shape[1] != 3:
+            raise ValueError(f"Macenko {what} expects 3 channels in dim 1 (NCHW), got C={images.shape[1]} with shape {tuple(images.shape)}")
+
+    def transform(self, images: torch.Tensor, stain_matrix: torch.Tensor, target_max_conc: torch.Tensor, *, normalize_to_0_1: bool = False) -> torch.Tensor:
+        images = images.to(self.device)
+        if tuple(stain_matrix.shape) != (3, 2):
+            raise ValueError(f"stain_matrix must have shape (3, 2), got {stain_matrix.shape}")
+        self._check_images(images, "transform")
+        sm = self._f32(stain_matrix)
+        tmc = self._f32(target_max_conc).flatten()
+        if tmc.numel() != 2:
+            raise ValueError(f"target_max_conc must have 2 elements, got {tmc.numel()}")
+        images = images.contiguous()
+        n, _, h, w = images.shape
+        code = _dtype_code(images)
+        out_dtype = torch.float32 if (normalize_to_0_1 and images.dtype == torch.uint8) else images.dtype
+        out = torch.empty((n, 3, h, w), dtype=out_dtype, device=self.device)
+        if n == 0 or h * w == 0:
+            return out
+        with torch.cuda.device(self.device):
+            nbytes = self._lib.sx_macenko_workspace_bytes(n, h, w)
+            ws = self._scratch.get(nbytes, self.device)
+            flags = _native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0
+            rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),
+                                                flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_transform")
+        self.last_workspace = ws
+        return out
+
+    def compute_reference_stain_matrix(self, images: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """Pooled stain estimate ``(HE (3,2), maxC (2,))`` (compute_reference_stain_matrix_torch, :463-519)."""
+        images = images.to(self.device)
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"Macenko fit expects NCHW with C=3, got shape {tuple(images.shape)}")
+        images = images.contiguous()
+        n, _, h, w = images.shape
+        he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
+        max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            nbytes = self._lib.sx_macenko_workspace_bytes(n, h, w)
+            ws = self._scratch.get(nbytes, self.device)
+            rc = self._lib.sx_macenko_fit(images.data_ptr(), _dtype_code(images), n, h, w, he.data_ptr(), max_c.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_fit")
+        self.last_workspace = ws
+        return he, max_c
+
+    # name kept so code written against the reference's torch class keeps working
+    compute_reference_stain_matrix_torch = compute_reference_stain_matrix
+
+    def tile_params(self, n_groups: int) -> dict[str, torch.Tensor]:
+        """Intermediates of the last transform (per tile) or fit (one pooled group); used by tests."""
+        if self.last_workspace is None:
+            raise RuntimeError("no transform / fit has run on this backend yet")
+        raw = torch.empty((n_groups, _native.MACENKO_PARAM_FLOATS), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.sx_macenko_tile_params(self.last_workspace.data_ptr(), n_groups, raw.data_ptr(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_tile_params")
+        raw = raw.cpu()
+        return {"n_kept": raw[:, 0].long(), "use_all": raw[:, 1].long(), "vecs": raw[:, 2:8].reshape(-1, 3, 2), "phi_lo": raw[:, 8],
+                "phi_hi": raw[:, 9], "he": raw[:, 10:16].reshape(-1, 3, 2), "max_c": raw[:, 16:18], "fell_back": raw[:, 18].long(),
+                "n_candidates": raw[:, 19:23].long(), "cov": raw[:, 23:32].reshape(-1, 3, 3), "stamps_us": raw[:, 32:48]}
+
+
+class ReinhardHIP(TorchHIPBackendBase):
+    """Reinhard LAB statistics matching on the GPU (numerics of ReinhardTorch, torch_backend.py:304-355)."""
+
+    @staticmethod
+    def _check(images: torch.Tensor) -> None:
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"Reinhard expects NCHW images with C=3, got shape {tuple(images.shape)}")
+
+    def compute_reference_mean_std(self, images: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        images = images.to(self.device)
+        self._check(images)
+        images = images.contiguous()
+        n, _, h, w = images.shape
+        mean = torch.empty(3, dtype=torch.float32, device=self.device)
+        std = torch.empty(3, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_reinhard_fit(images.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(), std.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_reinhard_fit")
+        return mean, std
+
+    compute_reference_mean_std_torch = compute_reference_mean_std
+
+    def transform(self, images: torch.Tensor, reference_mean: torch.Tensor, reference_std: torch.Tensor) -> torch.Tensor:
+        images = images.to(self.device)
+        self._check(images)
+        images = images.contiguous()
+        mean, std = self._f32(reference_mean).flatten(), self._f32(reference_std).flatten()
+        if mean.numel() != 3 or std.numel() != 3:
+            raise ValueError("reference_mean / reference_std must have 3 elements")
+        n, _, h, w = images.shape
+        out = torch.empty_like(images)
+        if images.numel() == 0:
+            return out
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_reinhard_transform(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(),
+                                                 std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_reinhard_transform")
+        return out
+
+
+class HistogramMatchingHIP(TorchHIPBackendBase):
+    """Histogram matching on the GPU (numerics of HistogramMatchingTorch, torch_backend.py:134-301)."""
+
+    def __init__(self, device: str | torch.device | None = None, channel_axis: int = 1):
+        super().__init__(device)
+        self.channel_axis = channel_axis
+        self.last_workspace: torch.Tensor | None = None
+
+    def _channels_last(self, images: torch.Tensor) -> bool:
+        return self.channel_axis == -1 or (self.channel_axis == 3 and images.ndim == 4)      # torch_backend.py:182
+
+    def _dims(self, images: torch.Tensor) -> tuple[int, int, int, bool]:
+        if images.dim() != 4:
+            raise ValueError(f"HistogramMatching expects 4D images, got shape {tuple(images.shape)}")
+        last = self._channels_last(images)
+        chans = images.shape[-1] if last else images.shape[1]
+        if chans != 3:
+            raise ValueError(f"HistogramMatching expects 3 channels, got {chans} with shape {tuple(images.shape)}")
+        n, h, w = (images.shape[0], images.shape[1], images.shape[2]) if last else (images.shape[0], images.shape[2], images.shape[3])
+        return n, h, w, last
+
+    def compute_reference_histograms(self, images: torch.Tensor) -> list[torch.Tensor]:
+        """Three normalised 256-bin histograms, what ``transform`` receives (torch_backend.py:139-160)."""
+        images = images.to(self.device).contiguous()
+        n, h, w, last = self._dims(images)
+        hists = torch.empty((3, 256), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_hm_fit(images.data_ptr(), _dtype_code(images), n, h, w, int(last), hists.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     _native.stream_ptr(self.device))
+        _native.check(rc, "sx_hm_fit")
+        return [hists[c] for c in range(3)]
+
+    def _stack_reference(self, reference_histogram, chans: int) -> torch.Tensor:
+        # list -> (C,256): pad with the first histogram / trim (torch_cuda_backend.py:51-74)
+        if isinstance(reference_histogram, (list, tuple)):
+            if len(reference_histogram) == 0:
+                raise ValueError("reference_histogram list cannot be empty")
+            for i, hist in enumerate(reference_histogram):
+                if not isinstance(hist, torch.Tensor):
+                    raise TypeError(f"reference_histogram[{i}] must be a torch.Tensor, got {type(hist)}")
+                if hist.dim() != 1 or hist.size(0) != 256:
+                    raise ValueError(f"Each histogram in reference_histogram list must be 1D with 256 elements. Got histogram at index {i} with shape {hist.shape}")
+            rows = [h.to(self.device) for h in reference_histogram]
+            while len(rows) < chans:
+                rows.append(rows[0])
+            ref = torch.stack(rows[:chans], dim=0)
+        else:
+            ref = reference_histogram.to(self.device)
+            if ref.dim() != 1 or ref.size(0) != 256:
+                raise ValueError(f"reference_histogram must be 1D with 256 elements. Got shape {ref.shape}")
+            ref = ref.unsqueeze(0).expand(chans, 256)
+        return ref.to(torch.float32).contiguous()
+
+    def transform(self, images: torch.Tensor, reference_histogram) -> torch.Tensor:
+        images = images.to(self.device).contiguous()
+        n, h, w, last = self._dims(images)
+        ref = self._stack_reference(reference_histogram, 3)
+        out = torch.empty_like(images)
+        if images.numel() == 0:
+            return out
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_hm_transform(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, int(last), ref.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_hm_transform")
+        self.last_workspace = ws
+        return out
+
+    def tables(self) -> dict[str, torch.Tensor]:
+        """Pooled integer source histogram (3,256) and float LUT (3,256) of the last transform."""
+        ws = self.last_workspace
+        counts = ws[: 3 * 256 * 4].view(torch.int32).reshape(3, 256).cpu().long()
+        lut = ws[3 * 256 * 4 : 2 * 3 * 256 * 4].view(torch.float32).reshape(3, 256).cpu()
+        return {"counts": counts, "lut": lut}

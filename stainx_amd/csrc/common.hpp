@@ -1,0 +1,105 @@
+// Shared device helpers for libstainx_hip (gfx950 only: wave64, no portability layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/stainx_hip.h"
+
+namespace sx {
+
+constexpr int kWave = 64;
+constexpr int kStreamThreads = 256;   // streaming kernels: 4 waves per workgroup
+
+// ---- error reporting (thread-local, never throws) ---------------------------------------------
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- element types ----------------------------------------------------------------------------
+// Input pixels become float "unit" values exactly as the reference's dtype gate does
+// (torch_backend.py:104-113): u8 -> float(u)/255 (correctly rounded division), floats -> float(x).
+template <typename T> struct Elem;
+template <> struct Elem<uint8_t> {
+    static __device__ __forceinline__ float load(uint8_t v) { return (float)v / 255.0f; }
+    static __device__ __forceinline__ uint8_t store(float v) { return (uint8_t)v; }  // trunc, like .to(uint8)
+};
+template <> struct Elem<__half> {
+    static __device__ __forceinline__ float load(__half v) { return __half2float(v); }
+    static __device__ __forceinline__ __half store(float v) { return __float2half(v); }  // RNE
+};
+template <> struct Elem<__hip_bfloat16> {
+    static __device__ __forceinline__ float load(__hip_bfloat16 v) { return __bfloat162float(v); }
+    static __device__ __forceinline__ __hip_bfloat16 store(float v) { return __float2bfloat16(v); }  // RNE
+};
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float load(float v) { return v; }
+    static __device__ __forceinline__ float store(float v) { return v; }
+};
+template <> struct Elem<double> {
+    static __device__ __forceinline__ float load(double v) { return (float)v; }   // .float(): RNE
+    static __device__ __forceinline__ double store(float v) { return (double)v; }
+};
+
+// A naturally aligned pack of V elements moved by one load/store instruction
+// (f32 x4 = 16 B/lane, bf16/f16 x4 = 8 B, u8 x4 = 4 B, f64 x4 = 2 x 16 B).
+template <typename T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
+
+template <typename T, int V>
+__device__ __forceinline__ void load_unit(const T* __restrict__ p, float (&out)[V]) {
+    if constexpr (V == 1) {
+        out[0] = Elem<T>::load(p[0]);
+    } else {
+        const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(p);
+#pragma unroll
+        for (int i = 0; i < V; ++i) out[i] = Elem<T>::load(pk.v[i]);
+    }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void store_pack(T* __restrict__ p, const T (&vals)[V]) {
+    if constexpr (V == 1) {
+        p[0] = vals[0];
+    } else {
+        Pack<T, V> pk;
+#pragma unroll
+        for (int i = 0; i < V; ++i) pk.v[i] = vals[i];
+        *reinterpret_cast<Pack<T, V>*>(p) = pk;
+    }
+}
+
+// ---- order-preserving uint32 image of a float (radix / bracket selection keys) ------------------
+__device__ __forceinline__ uint32_t float_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// ---- wave64 / workgroup reductions ---------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;   // lane 0 holds the sum
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// Position of this lane among the set lanes of `mask` below it.
+__device__ __forceinline__ uint32_t rank_in_mask(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+}  // namespace sx

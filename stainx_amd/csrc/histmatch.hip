@@ -1,0 +1,255 @@
+// Histogram matching for MI355X (gfx950): wavefront-private LDS histograms + fused LUT apply.
+//
+// Numerics follow HistogramMatchingTorch (rendeirolab/stainx src/stainx/backends/torch_backend.py:
+// 134-301): pixels become uint8 grey levels (floats: trunc(clamp(x*255,0,255)), :115-120), one
+// 256-bin histogram per channel pooled over the WHOLE batch (:229-236), source CDF vs reference CDF
+// -> 256-entry float LUT with linear interpolation (:254-281), gather (:285), and the output range /
+// dtype rules (:288-298).
+//
+// Kernels: (1) histogram -- 16-byte loads, one LDS sub-histogram per wave so lanes of different waves
+// never contend, integer adds only (bit-exact, order independent); (2) one small workgroup builds
+// the 3 x 256 LUT (sequential double-precision prefix sums rounded to float per entry, exactly what
+// torch.cumsum does on CPU floats) and the LUT in the OUTPUT element type; (3) apply -- LDS-resident
+// typed LUT, 16-byte loads and stores, writes the final dtype directly (the reference's native path
+// takes three more passes: histogram_matching.cu:153-166).
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace sx {
+namespace histmatch {
+
+constexpr int kBins = 256;
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / kWave;
+
+struct alignas(256) Tables {
+    uint32_t counts[3][kBins];      // pooled integer histogram of the source batch
+    float lut[3][kBins];            // float LUT (torch_backend.py:276-281)
+    uint64_t typed_lut[3][kBins];   // LUT already converted to the output element (low bytes)
+};
+
+struct Layout {
+    int64_t n_tiles, pixels;        // pixels per tile (H*W)
+    int channels_last;
+    __device__ __forceinline__ int channel_of(int64_t e) const { return channels_last ? (int)(e % 3) : (int)((e / pixels) % 3); }
+    __host__ __device__ int64_t elements() const { return n_tiles * 3 * pixels; }
+};
+
+template <typename T>
+__device__ __forceinline__ uint32_t grey_level(T v) {
+    if constexpr (sizeof(T) == 1) {
+        return (uint32_t)v;
+    } else {
+        float x;
+        if constexpr (sizeof(T) == 8) x = (float)v; else x = Elem<T>::load(v);
+        return (uint32_t)fminf(fmaxf(x * 255.0f, 0.0f), 255.0f);     // torch_backend.py:119 (trunc)
+    }
+}
+
+template <typename T> struct VecOf { static constexpr int n = 16 / sizeof(T); };   // elements per 16-byte load
+
+template <typename T, bool kVec>
+__global__ __launch_bounds__(kThreads) void histogram_kernel(const T* __restrict__ images, Layout lay, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[kWaves][3][kBins];
+    for (int i = threadIdx.x; i < kWaves * 3 * kBins; i += kThreads) (&hist[0][0][0])[i] = 0;
+    __syncthreads();
+    uint32_t(*mine)[kBins] = hist[threadIdx.x / kWave];
+    const int64_t total = lay.elements();
+    constexpr int V = kVec ? VecOf<T>::n : 1;
+    const int64_t stride = (int64_t)gridDim.x * kThreads * V;
+    for (int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * V; e < total; e += stride) {
+        if constexpr (kVec) {
+            const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(images + e);
+            if (lay.channels_last) {
+                int c = (int)(e % 3);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    atomicAdd(&mine[c][grey_level<T>(pk.v[i])], 1u);
+                    c = c == 2 ? 0 : c + 1;
+                }
+            } else {
+                const int c = lay.channel_of(e);          // pixels % V == 0: a pack never straddles planes
+#pragma unroll
+                for (int i = 0; i < V; ++i) atomicAdd(&mine[c][grey_level<T>(pk.v[i])], 1u);
+            }
+        } else {
+            atomicAdd(&mine[lay.channel_of(e)][grey_level<T>(images[e])], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * kBins; i += kThreads) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) s += (&hist[w][0][0])[i];
+        if (s) atomicAdd(&counts[i], s);
+    }
+}
+
+// fit: normalised histogram  counts / (sum(counts) + 1e-8)  in float32 (torch_backend.py:139-141)
+__global__ void normalise_kernel(const uint32_t* __restrict__ counts, float* __restrict__ hist_out) {
+    const int c = blockIdx.x;
+    __shared__ float total_s;
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int b = 0; b < kBins; ++b) t += (double)(float)counts[c * kBins + b];
+        total_s = (float)t + 1e-8f;
+    }
+    __syncthreads();
+    hist_out[c * kBins + threadIdx.x] = (float)counts[c * kBins + threadIdx.x] / total_s;
+}
+
+template <typename O> __device__ __forceinline__ uint64_t pack_elem(O v) {
+    uint64_t bits = 0;
+    __builtin_memcpy(&bits, &v, sizeof(O));
+    return bits;
+}
+
+// One workgroup of 256 threads per channel.  InT decides the range rules of the output (:288-298).
+template <typename T>
+__global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, const float* __restrict__ ref_hist, double num_pixels) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    __shared__ float src_cdf[kBins], ref_cdf[kBins];
+    __shared__ float ref_total_s;
+    if (t == 0) {
+        // source: counts / float(num_pixels + 1e-8), running sum in double rounded per entry (:235-236)
+        const float denom = (float)(num_pixels + 1e-8);
+        double run = 0.0;
+        for (int b = 0; b < kBins; ++b) {
+            run += (double)((float)tab->counts[c][b] / denom);
+            src_cdf[b] = (float)run;
+        }
+    } else if (t == 64) {
+        // reference: h / (sum(h) + 1e-8), then the same prefix sum (:222-223)
+        double tot = 0.0;
+        for (int b = 0; b < kBins; ++b) tot += (double)ref_hist[c * kBins + b];
+        const float denom = (float)tot + 1e-8f;
+        ref_total_s = denom;
+        double run = 0.0;
+        for (int b = 0; b < kBins; ++b) {
+            run += (double)(ref_hist[c * kBins + b] / denom);
+            ref_cdf[b] = (float)run;
+        }
+    }
+    __syncthreads();
+    const float s = src_cdf[t];
+    // searchsorted(right=False): first index with ref_cdf[idx] >= s; clamp to [1,255] (:260-261)
+    int lo = 0, hi = kBins;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ref_cdf[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    const int idx = min(max(lo, 1), kBins - 1);
+    const float q_lo = ref_cdf[idx - 1], q_hi = ref_cdf[idx];
+    const float diff = q_hi - q_lo;
+    const float alpha = diff > 1e-10f ? (s - q_lo) / diff : 0.0f;                    // :272-273
+    float v = (float)(idx - 1) + alpha * ((float)idx - (float)(idx - 1));             // :276
+    if (s <= ref_cdf[0]) v = 0.0f;                                                    // :268, :279
+    if (s >= ref_cdf[kBins - 1]) v = 255.0f;                                          // :269, :280
+    v = fminf(fmaxf(v, 0.0f), 255.0f);                                                // :281
+    tab->lut[c][t] = v;
+    if constexpr (sizeof(T) == 1) {
+        tab->typed_lut[c][t] = pack_elem<uint8_t>((uint8_t)v);                        // stays 0..255, truncated
+    } else {
+        const float unit = fminf(fmaxf(v / 255.0f, 0.0f), 1.0f);                      // :291, :296
+        if constexpr (sizeof(T) == 8) tab->typed_lut[c][t] = pack_elem<double>((double)unit);
+        else tab->typed_lut[c][t] = pack_elem<T>(Elem<T>::store(unit));
+    }
+}
+
+template <typename T, bool kVec>
+__global__ __launch_bounds__(kThreads) void apply_kernel(const T* __restrict__ images, T* __restrict__ out, Layout lay, const Tables* __restrict__ tab) {
+    __shared__ T lut[3][kBins];
+    for (int i = threadIdx.x; i < 3 * kBins; i += kThreads) {
+        const uint64_t bits = (&tab->typed_lut[0][0])[i];
+        T v;
+        __builtin_memcpy(&v, &bits, sizeof(T));
+        (&lut[0][0])[i] = v;
+    }
+    __syncthreads();
+    const int64_t total = lay.elements();
+    constexpr int V = kVec ? VecOf<T>::n : 1;
+    const int64_t stride = (int64_t)gridDim.x * kThreads * V;
+    for (int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * V; e < total; e += stride) {
+        if constexpr (kVec) {
+            const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(images + e);
+            Pack<T, V> res;
+            int c = lay.channel_of(e);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                res.v[i] = lut[c][grey_level<T>(pk.v[i])];
+                if (lay.channels_last) c = c == 2 ? 0 : c + 1;
+            }
+            *reinterpret_cast<Pack<T, V>*>(out + e) = res;
+        } else {
+            out[e] = lut[lay.channel_of(e)][grey_level<T>(images[e])];
+        }
+    }
+}
+
+static size_t workspace_bytes() { return sizeof(Tables); }
+
+template <typename T>
+static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, void* ws, hipStream_t stream) {
+    Layout lay{n, h * w, channels_last};
+    Tables* tab = static_cast<Tables*>(ws);
+    const T* in = static_cast<const T*>(images);
+    constexpr int V = VecOf<T>::n;
+    const int64_t total = lay.elements();
+    // vector path: 16-byte aligned base, and a pack never crosses a channel plane
+    const bool vec = (reinterpret_cast<uintptr_t>(images) % 16 == 0) && (!out || reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
+                     (channels_last ? (total % V == 0) : (lay.pixels % V == 0));
+    const int64_t per_block = (int64_t)kThreads * (vec ? V : 1) * 4;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + per_block - 1) / per_block, 256 * 8);
+    if (hipMemsetAsync(tab->counts, 0, sizeof(tab->counts), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
+    if (vec)
+        hipLaunchKernelGGL((histogram_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
+    else
+        hipLaunchKernelGGL((histogram_kernel<T, false>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
+    if (hist_out) {
+        hipLaunchKernelGGL(normalise_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], hist_out);
+        return check_launch("histogram fit");
+    }
+    hipLaunchKernelGGL((lut_kernel<T>), dim3(3), dim3(kBins), 0, stream, tab, ref_hist, (double)(n * h * w));
+    if (vec)
+        hipLaunchKernelGGL((apply_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, static_cast<T*>(out), lay, tab);
+    else
+        hipLaunchKernelGGL((apply_kernel<T, false>), dim3(grid), dim3(kThreads), 0, stream, in, static_cast<T*>(out), lay, tab);
+    return check_launch("histogram transform");
+}
+
+static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, void* ws, size_t ws_bytes, void* stream_ptr) {
+    if (!images) return fail(SX_ERR_BAD_ARG, "images pointer is null");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(SX_ERR_BAD_ARG, "images must have positive sizes, got N=%lld H=%lld W=%lld", (long long)n, (long long)h, (long long)w);
+    if (!ws || ws_bytes < workspace_bytes()) return fail(SX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", workspace_bytes(), ws_bytes);
+    if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(SX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    switch (dtype) {
+        case SX_U8: return run<uint8_t>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
+        case SX_F16: return run<__half>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
+        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
+        case SX_F32: return run<float>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
+        case SX_F64: return run<double>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
+        default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    }
+}
+
+}  // namespace histmatch
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" size_t sx_hm_workspace_bytes(int64_t n, int64_t h, int64_t w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    return histmatch::workspace_bytes();
+}
+
+extern "C" int sx_hm_fit(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, float* hist_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!hist_out) return fail(SX_ERR_BAD_ARG, "hist_out pointer is null");
+    return histmatch::dispatch(images, nullptr, dtype, n, h, w, channels_last, nullptr, hist_out, ws, ws_bytes, stream);
+}
+
+extern "C" int sx_hm_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, void* ws, size_t ws_bytes, void* stream) {
+    if (!out || !ref_hist) return fail(SX_ERR_BAD_ARG, "out / ref_hist pointer is null");
+    return histmatch::dispatch(images, out, dtype, n, h, w, channels_last, ref_hist, nullptr, ws, ws_bytes, stream);
+}

@@ -1,0 +1,255 @@
+// Reinhard LAB statistics matching for MI355X (gfx950).
+//
+// Numerics follow ReinhardTorch (rendeirolab/stainx src/stainx/backends/torch_backend.py:17-101,
+// 304-355): sRGB -> linear -> XYZ/D65 -> scaled LAB, mean / unbiased std pooled over the WHOLE batch
+// (N,H,W), (lab-mu)/(sigma+1e-8)*sigma_ref+mu_ref, back to sRGB, clamp, cast.
+//
+// Two streaming kernels per transform: (1) LAB sums and sums of squares, fp64 across lanes /
+// workgroups, finished by the last workgroup to arrive; (2) the fused normalise + inverse transform.
+// LAB is recomputed in pass 2 instead of being stored: 24 VALU-cheap transcendentals per pixel are
+// cheaper than a 12 B/px round trip through HBM.
+#include "common.hpp"
+
+namespace sx {
+namespace reinhard {
+
+constexpr int kIters = 8;
+constexpr int kSums = 6;   // per channel: sum, sum of squares (about a fixed shift)
+
+struct alignas(256) State {
+    double sums[kSums];
+    float mean[3], stdv[3];      // source statistics
+    unsigned int arrivals;
+};
+
+// pow through v_log_f32 / v_exp_f32; x > 0
+__device__ __forceinline__ float fast_pow(float x, float e) { return exp2f(e * __log2f(x)); }
+
+// Centre of the LAB accumulators: keeps sum-of-squares small (values are shifted, not rescaled).
+__device__ __forceinline__ float lab_shift(int c) { return c == 0 ? 128.0f : 128.0f; }
+
+__device__ __forceinline__ void rgb_to_lab(const float rgb[3], float lab[3]) {
+    float lin[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)   // torch_backend.py:28-29
+        lin[c] = rgb[c] > 0.04045f ? fast_pow((rgb[c] + 0.055f) / 1.055f, 2.4f) : rgb[c] / 12.92f;
+    // torch_backend.py:32-38
+    const float x = (0.412453f * lin[0] + 0.357580f * lin[1] + 0.180423f * lin[2]) / 0.95047f;
+    const float y = (0.212671f * lin[0] + 0.715160f * lin[1] + 0.072169f * lin[2]);
+    const float z = (0.019334f * lin[0] + 0.119193f * lin[1] + 0.950227f * lin[2]) / 1.08883f;
+    const float xyz[3] = {x, y, z};
+    float f[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)   // torch_backend.py:41-42
+        f[c] = xyz[c] > 0.008856f ? fast_pow(xyz[c], 1.0f / 3.0f) : 7.787f * xyz[c] + 16.0f / 116.0f;
+    lab[0] = (116.0f * f[1] - 16.0f) * 2.55f;       // :51
+    lab[1] = 500.0f * (f[0] - f[1]) + 128.0f;       // :52
+    lab[2] = 200.0f * (f[1] - f[2]) + 128.0f;       // :53
+}
+
+__device__ __forceinline__ float f_inv(float t) { return t > 0.2068966f ? t * t * t : (t - 16.0f / 116.0f) / 7.787f; }   // :78-80
+
+__device__ __forceinline__ void lab_to_rgb(const float lab[3], float rgb[3]) {
+    const float l = lab[0] / 2.55f, a = lab[1] - 128.0f, b = lab[2] - 128.0f;   // :70-72
+    const float fy = (l + 16.0f) / 116.0f, fx = a / 500.0f + fy, fz = fy - b / 200.0f;
+    const float x = f_inv(fx) * 0.95047f, y = f_inv(fy), z = f_inv(fz) * 1.08883f;
+    const float lin[3] = {3.2404542f * x - 1.5371385f * y - 0.4985314f * z, -0.9692660f * x + 1.8760108f * y + 0.0415560f * z,
+                          0.0556434f * x - 0.2040259f * y + 1.0572252f * z};   // :89-91
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {   // :93-96
+        const float v = lin[c] > 0.0031308f ? 1.055f * fast_pow(lin[c], 1.0f / 2.4f) - 0.055f : 12.92f * lin[c];
+        rgb[c] = fminf(fmaxf(v, 0.0f), 1.0f);
+    }
+}
+
+struct Geometry {
+    int64_t n_tiles, pixels;
+    int blocks_per_tile, chunk;
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, State* __restrict__ st, double* __restrict__ partial, float* __restrict__ mean_out, float* __restrict__ std_out) {
+    const int64_t tile = blockIdx.x / g.blocks_per_tile;
+    const int chunk_id = blockIdx.x % g.blocks_per_tile;
+    const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
+    const T* img = images + tile * 3 * g.pixels;
+    double acc[kSums];
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
+        float u[3][V];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+        float s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float rgb[3] = {u[0][i], u[1][i], u[2][i]};
+            float lab[3];
+            rgb_to_lab(rgb, lab);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float d = lab[c] - lab_shift(c);
+                s[c] += d;
+                q[c] = fmaf(d, d, q[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc[c] += (double)s[c];
+            acc[3 + c] += (double)q[c];
+        }
+    }
+    __shared__ double red[kStreamThreads / kWave][kSums];
+    __shared__ bool last;
+    const int wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane_id() == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSums) {
+        double s = 0.0;
+        for (int w = 0; w < kStreamThreads / kWave; ++w) s += red[w][threadIdx.x];
+        // write-through (sc1) store: visible to the finishing workgroup on any XCD once its counter add lands
+        __hip_atomic_store(&partial[(int64_t)blockIdx.x * kSums + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int ticket = __hip_atomic_fetch_add(&st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    // last workgroup: sum the partials in index order (deterministic), finish mean / unbiased std
+    if (threadIdx.x < kSums) {
+        double s = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&partial[(int64_t)b * kSums + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[0][threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        const double n = (double)g.n_tiles * (double)g.pixels;
+        const double m = red[0][c] / n;
+        const double var = n > 1.0 ? (red[0][3 + c] - red[0][c] * m) / (n - 1.0) : __longlong_as_double(0x7ff8000000000000ll);   // torch.std of one value is nan
+        const float mean = (float)(m + (double)lab_shift(c)), sd = (float)sqrt(fmax(var, 0.0));
+        st->mean[c] = mean;
+        st->stdv[c] = sd;
+        if (mean_out) {
+            mean_out[c] = mean;
+            std_out[c] = sd;
+        }
+    }
+    if (threadIdx.x == 0) st->arrivals = 0;   // ready for the next call on this workspace
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restrict__ images, T* __restrict__ out, Geometry g, const State* __restrict__ st, const float* __restrict__ ref_mean, const float* __restrict__ ref_std) {
+    const int64_t tile = blockIdx.x / g.blocks_per_tile;
+    const int chunk_id = blockIdx.x % g.blocks_per_tile;
+    const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
+    const T* img = images + tile * 3 * g.pixels;
+    T* dst = out + tile * 3 * g.pixels;
+    float mu[3], sd_eps[3], rs[3], rm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        mu[c] = st->mean[c];
+        sd_eps[c] = st->stdv[c] + 1e-8f;     // :349  (divide, not reciprocal-multiply, below)
+        rs[c] = ref_std[c];
+        rm[c] = ref_mean[c];
+    }
+    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
+        float u[3][V];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+        T res[3][V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float rgb[3] = {u[0][i], u[1][i], u[2][i]};
+            float lab[3], back[3];
+            rgb_to_lab(rgb, lab);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lab[c] = ((lab[c] - mu[c]) / sd_eps[c]) * rs[c] + rm[c];   // :349
+            lab_to_rgb(lab, back);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if constexpr (sizeof(T) == 1)
+                    res[c][i] = Elem<T>::store(fminf(fmaxf(back[c] * 255.0f, 0.0f), 255.0f));   // :125, :131
+                else
+                    res[c][i] = Elem<T>::store(back[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) store_pack<T, V>(dst + c * g.pixels + p, res[c]);
+    }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static int blocks_for(int64_t pixels) {
+    const int64_t chunk = (int64_t)kStreamThreads * 4 * kIters;
+    return (int)((pixels + chunk - 1) / chunk);
+}
+static size_t workspace_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(State), 256) + align_up(sizeof(double) * kSums * (size_t)blocks_for(pixels) * (size_t)n, 256); }
+
+__global__ void init_state_kernel(State* st) { st->arrivals = 0; }
+
+template <typename T>
+static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, float* mean_out, float* std_out, void* ws, hipStream_t stream) {
+    Geometry g{n, h * w, blocks_for(h * w), kStreamThreads * 4 * kIters};
+    State* st = static_cast<State*>(ws);
+    double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + align_up(sizeof(State), 256));
+    const bool vec = (g.pixels % 4 == 0) && (reinterpret_cast<uintptr_t>(images) % (sizeof(T) * 4) == 0) && (!out || reinterpret_cast<uintptr_t>(out) % (sizeof(T) * 4) == 0);
+    const unsigned grid = (unsigned)(n * g.blocks_per_tile);
+    const T* in = static_cast<const T*>(images);
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, st);
+    if (vec)
+        hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, mean_out, std_out);
+    else
+        hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, mean_out, std_out);
+    if (out) {
+        if (vec)
+            hipLaunchKernelGGL((apply_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, static_cast<T*>(out), g, st, ref_mean, ref_std);
+        else
+            hipLaunchKernelGGL((apply_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, static_cast<T*>(out), g, st, ref_mean, ref_std);
+    }
+    return check_launch("reinhard");
+}
+
+static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* rm, const float* rs, float* mo, float* so, void* ws, size_t ws_bytes, void* stream_ptr) {
+    if (!images) return fail(SX_ERR_BAD_ARG, "images pointer is null");
+    if (n <= 0 || h <= 0 || w <= 0) return fail(SX_ERR_BAD_ARG, "images must be (N,3,H,W) with positive sizes");
+    const size_t need = workspace_bytes(n, h * w);
+    if (!ws || ws_bytes < need) return fail(SX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, ws_bytes);
+    if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(SX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    switch (dtype) {
+        case SX_U8: return run<uint8_t>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
+        case SX_F16: return run<__half>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
+        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
+        case SX_F32: return run<float>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
+        case SX_F64: return run<double>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
+        default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    }
+}
+
+}  // namespace reinhard
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" size_t sx_reinhard_workspace_bytes(int64_t n, int64_t h, int64_t w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    return reinhard::workspace_bytes(n, h * w);
+}
+
+extern "C" int sx_reinhard_fit(const void* images, int dtype, int64_t n, int64_t h, int64_t w, float* mean_out, float* std_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!mean_out || !std_out) return fail(SX_ERR_BAD_ARG, "mean_out / std_out pointer is null");
+    return reinhard::dispatch(images, nullptr, dtype, n, h, w, nullptr, nullptr, mean_out, std_out, ws, ws_bytes, stream);
+}
+
+extern "C" int sx_reinhard_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, void* ws, size_t ws_bytes, void* stream) {
+    if (!out || !ref_mean || !ref_std) return fail(SX_ERR_BAD_ARG, "out / ref_mean / ref_std pointer is null");
+    return reinhard::dispatch(images, out, dtype, n, h, w, ref_mean, ref_std, nullptr, nullptr, ws, ws_bytes, stream);
+}

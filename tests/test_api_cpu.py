@@ -1,0 +1,175 @@
+"""Host-side behaviour that needs no GPU: the C-ABI library loads and exports every declared symbol,
+backend-id validation, the StainNormalizerTransform validation matrix (reference
+tests/torch_interface/test_stain_normalizer_transform.py and tests/test_normalizer_template_unit.py),
+and that the product never falls back to the CPU."""
+from __future__ import annotations
+
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+import stainx_amd
+from stainx_amd import HistogramMatching, Macenko, Reinhard, StainNormalizerTransform, _native
+from stainx_amd.utils import ChannelFormatConverter
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "stainx_hip.h").read_text()
+    declared = set(re.findall(r"\b(sx_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    assert _native.library_available(), _native._load_error
+    lib = ctypes.CDLL(str(_native.LIB_PATH))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _native.require().sx_version() == _native.ABI_VERSION
+    # size queries are pure host functions
+    assert _native.require().sx_macenko_workspace_bytes(64, 512, 512) > 0
+    assert _native.require().sx_macenko_workspace_bytes(0, 512, 512) == 0
+    assert _native.require().sx_hm_workspace_bytes(1, 8, 8) >= 3 * 256 * 8
+
+
+def test_public_surface():
+    assert set(stainx_amd.__all__) >= {"Macenko", "Reinhard", "HistogramMatching", "StainNormalizerTransform", "StainNormalizerBase"}
+    for cls in (Macenko, Reinhard, HistogramMatching):
+        assert issubclass(cls, stainx_amd.StainNormalizerBase)
+        for method in ("fit", "transform", "fit_transform"):
+            assert callable(getattr(cls, method))
+
+
+def test_transform_requires_fit():
+    n = Reinhard(backend="torch_hip", device="cuda")
+    with pytest.raises(ValueError, match="fit"):
+        n.transform(torch.rand(1, 3, 8, 8))
+
+
+def test_backend_ids():
+    assert Macenko(device="cuda", backend="torch_cuda").backend == "torch_hip"       # the reference's id is an alias
+    assert Macenko(device="cuda").backend == "torch_hip"
+    with pytest.raises(ValueError, match="Unsupported backend"):
+        Macenko(backend="numpy")
+    with pytest.raises(ValueError, match="Unsupported backend 'torch'"):
+        Reinhard(backend="torch")
+    with pytest.raises(ValueError, match="precision must be"):
+        Macenko(precision="ultra")
+    assert Macenko(device="cuda", precision="fast")._get_backend_kwargs() == {"precision": "fast"}
+
+
+def test_no_cpu_fallback():
+    """A CPU device is refused by the backend itself; nothing is computed with torch ops instead."""
+    n = Reinhard(device="cpu")
+    with pytest.raises(ValueError, match="requires a CUDA"):
+        n.fit(torch.rand(1, 3, 8, 8))
+    if not torch.cuda.is_available():
+        with pytest.raises((RuntimeError, AssertionError, ValueError)):
+            Macenko(device="cuda").fit(torch.rand(1, 3, 8, 8))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_load_error", None)
+    monkeypatch.setenv("STAINX_HIP_LIB", str(tmp_path / "nope.so"))
+    assert not _native.library_available()
+    with pytest.raises(ImportError, match="not built or not loadable"):
+        _native.require()
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_load_error", None)
+    monkeypatch.delenv("STAINX_HIP_LIB")
+    assert _native.library_available()
+
+
+class TestPrepareForNormalizer:
+    def test_nhwc_batch_permute_keeps_n_and_device(self):
+        x = torch.randn(4, 32, 48, 3)
+        out = ChannelFormatConverter(channel_axis=-1).prepare_for_normalizer(x)
+        assert out.shape == (4, 3, 32, 48) and out.device == x.device
+        assert torch.allclose(out.permute(0, 2, 3, 1), x)
+
+    def test_hwc_gains_batch_axis(self):
+        assert ChannelFormatConverter(channel_axis=3).prepare_for_normalizer(torch.randn(8, 9, 3)).shape == (1, 3, 8, 9)
+
+    def test_channels_first_passthrough(self):
+        x = torch.randn(2, 3, 16, 16)
+        assert ChannelFormatConverter(channel_axis=1).prepare_for_normalizer(x).data_ptr() == x.data_ptr()
+
+    def test_unknown_channel_axis_raises(self):
+        with pytest.raises(ValueError, match="Unsupported channel_axis"):
+            ChannelFormatConverter(channel_axis=0)
+
+    def test_to_hwc(self):
+        x = torch.arange(2 * 3 * 4 * 5).reshape(2, 3, 4, 5)
+        assert ChannelFormatConverter(1).to_hwc(x[:1], squeeze_batch=True).shape == (4, 5, 3)
+
+
+class TestTransformValidation:
+    """The constructor / layout validation matrix of reference transforms.py:93-140, 200-216."""
+
+    def ref(self):
+        return (torch.rand(1, 3, 16, 16) * 255).round().to(torch.uint8)
+
+    def test_bad_mode(self):
+        with pytest.raises(ValueError, match="Unsupported mode"):
+            StainNormalizerTransform(method="reinhard", mode="online")
+
+    def test_unknown_method(self):
+        with pytest.raises(ValueError, match="Unknown method"):
+            StainNormalizerTransform(method="vahadane", mode="batch")
+
+    def test_reference_mode_needs_reference(self):
+        with pytest.raises(ValueError, match="requires a reference tensor"):
+            StainNormalizerTransform(method="reinhard", mode="reference")
+
+    def test_normalize_to_0_1_rejected_for_reinhard(self):
+        with pytest.raises(ValueError, match="only applies to Macenko"):
+            StainNormalizerTransform(method="reinhard", mode="batch", normalize_to_0_1=True)
+        with pytest.raises(ValueError, match="only applies to Macenko"):
+            StainNormalizerTransform(mode="batch", normalizer=Reinhard(device="cuda"), normalize_to_0_1=True)
+
+    def test_gpu_backend_plus_cpu_device_rejected(self):
+        for backend in ("torch_hip", "torch_cuda"):
+            with pytest.raises(ValueError, match="requires a CUDA device"):
+                StainNormalizerTransform(method="reinhard", mode="batch", backend=backend, device="cpu")
+
+    def test_macenko_defaults_and_prebuilt_flag(self):
+        t = StainNormalizerTransform(method="macenko", mode="batch")
+        assert t.normalizer.normalize_to_0_1 is True
+        assert StainNormalizerTransform(method="macenko", mode="batch", normalize_to_0_1=False).normalizer.normalize_to_0_1 is False
+        n = Macenko(device="cuda", normalize_to_0_1=True)
+        assert StainNormalizerTransform(mode="batch", normalizer=n, normalize_to_0_1=False).normalizer.normalize_to_0_1 is False
+        n2 = Macenko(device="cuda", normalize_to_0_1=False)
+        assert StainNormalizerTransform(mode="batch", normalizer=n2).normalizer.normalize_to_0_1 is False   # left alone
+
+    def test_macenko_rejects_nhwc_channel_axis(self):
+        with pytest.raises(ValueError, match="only supported for histogram_matching"):
+            StainNormalizerTransform(method="macenko", mode="batch", channel_axis=-1)
+        with pytest.raises(ValueError, match="only supported for histogram_matching"):
+            StainNormalizerTransform(mode="batch", normalizer=Reinhard(device="cuda"), channel_axis=3)
+
+    def test_prebuilt_hm_channel_axis(self):
+        n = HistogramMatching(device="cuda", channel_axis=-1)
+        assert StainNormalizerTransform(mode="batch", normalizer=n).channel_axis == -1
+        with pytest.raises(ValueError, match="conflicts with prebuilt"):
+            StainNormalizerTransform(mode="batch", normalizer=HistogramMatching(device="cuda", channel_axis=1), channel_axis=-1)
+
+    def test_layout_checks_happen_before_any_gpu_work(self):
+        t = StainNormalizerTransform(method="macenko", mode="batch")
+        with pytest.raises(ValueError, match="Expected NCHW"):
+            t((torch.rand(2, 16, 16, 3) * 255).to(torch.uint8))
+        with pytest.raises(ValueError, match="Expected CHW/NCHW"):
+            t(torch.rand(16, 16))
+        hm = StainNormalizerTransform(method="histogram_matching", mode="batch", channel_axis=-1)
+        with pytest.raises(ValueError, match="channels-last histogram matching expects"):
+            hm(torch.rand(2, 3, 16, 16))
+
+    def test_state_dict_has_no_fitted_parameters(self):
+        t = StainNormalizerTransform(method="macenko", mode="batch")
+        assert not any("stain" in k or "max_conc" in k for k in t.state_dict())
+
+    def test_batch_ref_index_out_of_range(self):
+        t = StainNormalizerTransform(method="reinhard", mode="batch", batch_ref_index=5, device="cpu")
+        with pytest.raises(IndexError, match="out of range"):
+            t(torch.rand(2, 3, 8, 8))

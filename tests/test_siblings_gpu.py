@@ -1,0 +1,137 @@
+"""GPU parity tests of the Reinhard and histogram-matching paths against the
+committed reference outputs and the CPU oracle."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stain_oracle as so
+from stainx_amd import synth
+from tests.conftest import TORCH_DTYPES, golden_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ Reinhard
+def test_reinhard_matches_reference_golden(dev, golden):
+    from stainx_amd.backends.torch_hip_backend import ReinhardHIP
+
+    g = golden("g4_reinhard.npz")
+    be = ReinhardHIP(dev)
+    for tag, hw, n in (("cfg1_512", (512, 512), 1), ("b2_128", (128, 128), 2), ("odd_67x45", (67, 45), 3)):
+        ref = synth.noise_u8((1, 3, *hw), 42)
+        src = synth.noise_u8((n, 3, *hw), 43)
+        for name in ("f32", "u8", "bf16"):
+            dt = TORCH_DTYPES[name]
+            rin, sin = synth.as_dtype(ref, dt).to(dev), synth.as_dtype(src, dt).to(dev)
+            mean, std = be.compute_reference_mean_std(rin)
+            np.testing.assert_allclose(mean.cpu().numpy(), g[f"{tag}_{name}_ref_mean"], rtol=0, atol=2e-3)   # LAB units (0..255)
+            np.testing.assert_allclose(std.cpu().numpy(), g[f"{tag}_{name}_ref_std"], rtol=1e-4, atol=1e-3)
+            out = be.transform(sin, torch.from_numpy(g[f"{tag}_{name}_ref_mean"]), torch.from_numpy(g[f"{tag}_{name}_ref_std"]))
+            assert out.dtype == dt and out.shape == sin.shape
+            got = out.cpu()
+            if f"{tag}_{name}_out" in g:
+                want = golden_tensor(g[f"{tag}_{name}_out"], name)
+            else:
+                want = golden_tensor(g[f"{tag}_{name}_out_sub"], name)
+                got = got.reshape(n, 3, -1)[:, :, ::61]
+            diff = (got.double() - want.double()).abs()
+            if name == "f32":
+                assert diff.max().item() <= 1e-4, (tag, diff.max().item())        # [0,1] scale
+            elif name == "u8":
+                assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 5e-3, tag
+            else:
+                assert diff.max().item() <= 2.0 ** -8 and (diff > 0).float().mean().item() < 2e-2, tag
+
+
+def test_reinhard_config1_fit_transform_vs_oracle(dev):
+    """BASELINE configs[0]: Reinhard fit + transform, 1x3x512x512 fp32."""
+    from stainx_amd import Reinhard
+
+    ref = synth.as_dtype(synth.noise_u8((1, 3, 512, 512), 42), torch.float32)
+    src = synth.as_dtype(synth.noise_u8((1, 3, 512, 512), 43), torch.float32)
+    norm = Reinhard(device=dev, backend="torch_hip")
+    out = norm.fit(ref.to(dev)).transform(src.to(dev))
+    mean, std = so.reinhard_fit(ref.numpy())
+    want = so.reinhard_transform(src.numpy(), mean, std)
+    np.testing.assert_allclose(norm._reference_mean.cpu().numpy(), mean, atol=2e-3)
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-4
+    # Beer-Lambert tiles, uint8, batch statistics are pooled over the batch (not per tile)
+    tiles = synth.he_batch(3, 96, 96, seed0=500, scale_step=0.1)
+    got = norm.fit(synth.reference_tile(96, 96).to(dev)).transform(tiles.to(dev)).cpu().numpy()
+    m2, s2 = so.reinhard_fit(synth.reference_tile(96, 96).numpy())
+    want = so.reinhard_transform(tiles.numpy(), m2, s2)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    solo = norm.transform(tiles[:1].to(dev)).cpu().numpy()
+    assert np.abs(solo.astype(int) - got[:1].astype(int)).max() > 1      # batch-coupled, like the reference
+
+
+# ------------------------------------------------------------------ histogram matching
+def test_histogram_matching_matches_reference_golden(dev, golden):
+    from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
+
+    g = golden("g5_histogram_matching.npz")
+    for tag in ("noise", "he"):
+        ref8, src8 = torch.from_numpy(g[f"{tag}_ref_u8"]), torch.from_numpy(g[f"{tag}_src_u8"])
+        for name in ("u8", "f32", "bf16"):
+            dt = TORCH_DTYPES[name]
+            for layout, axis in (("nchw", 1), ("nhwc", -1)):
+                be = HistogramMatchingHIP(dev, channel_axis=axis)
+                rin, sin = synth.as_dtype(ref8, dt), synth.as_dtype(src8, dt)
+                if axis == -1:
+                    rin, sin = rin.permute(0, 2, 3, 1).contiguous(), sin.permute(0, 2, 3, 1).contiguous()
+                key = f"{tag}_{name}_{layout}"
+                hists = be.compute_reference_histograms(rin.to(dev))
+                np.testing.assert_array_equal(torch.stack(hists).cpu().numpy(), g[f"{key}_ref_hists"])       # bit-exact
+                out = be.transform(sin.to(dev), hists)
+                want = golden_tensor(g[f"{key}_out"], name)
+                assert out.dtype == dt and out.shape == sin.shape
+                assert torch.equal(out.cpu(), want), key                                                      # bit-exact
+                if name == "u8" and axis == 1:
+                    tab = be.tables()
+                    np.testing.assert_array_equal(tab["counts"].numpy(), g[f"{tag}_counts"])                  # integer histogram
+                    present = g[f"{tag}_lut_u8_trunc"] >= 0
+                    np.testing.assert_array_equal(np.trunc(tab["lut"].numpy())[present], g[f"{tag}_lut_u8_trunc"][present])
+
+
+def test_histogram_matching_config3_properties(dev):
+    """BASELINE configs[2] shape family (uint8, 1024x1024 tiles; 8 tiles here, 64 in the bench): the pooled
+    histogram is an exact integer count, the LUT is monotone, and the result equals the oracle's."""
+    from stainx_amd import HistogramMatching
+
+    ref = synth.noise_u8((1, 3, 1024, 1024), 42)
+    src = synth.noise_u8((8, 3, 1024, 1024), 43)
+    hm = HistogramMatching(device=dev, backend="torch_hip")
+    out = hm.fit(ref.to(dev)).transform(src.to(dev))
+    tab = hm._get_backend_impl().tables()
+    counts = np.stack([np.bincount(src[:, c].reshape(-1).numpy(), minlength=256) for c in range(3)])
+    np.testing.assert_array_equal(tab["counts"].numpy(), counts)
+    assert int(tab["counts"].sum()) == src.numel()
+    assert bool((tab["lut"][:, 1:] >= tab["lut"][:, :-1]).all())
+    want = so.hm_transform(src.numpy(), so.hm_fit(ref.numpy()))
+    assert np.array_equal(out.cpu().numpy(), want)
+    # a single (256,) reference histogram applies to every channel (torch_backend.py:224-226)
+    one = hm._ref_histograms_256[0]
+    got1 = hm._get_backend_impl().transform(src[:1].to(dev), one)
+    want1 = so.hm_transform(src[:1].numpy(), one.cpu().numpy())
+    assert np.array_equal(got1.cpu().numpy(), want1)
+
+
+def test_histogram_matching_errors(dev):
+    from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
+
+    be = HistogramMatchingHIP(dev)
+    x = synth.noise_u8((1, 3, 16, 16), 1)
+    with pytest.raises(ValueError, match="cannot be empty"):
+        be.transform(x, [])
+    with pytest.raises(ValueError, match="256 elements"):
+        be.transform(x, torch.rand(128))
+    with pytest.raises(TypeError, match="must be a torch.Tensor"):
+        be.transform(x, [np.zeros(256)])
