@@ -75,6 +75,22 @@ int sx_macenko_fit(const void* images_dev, int dtype, int64_t n_tiles, int64_t h
 #define SX_MACENKO_PARAM_FLOATS 48
 int sx_macenko_tile_params(const void* workspace_dev, int64_t n_groups, float* params_out_dev, void* stream);
 
+/* Pooled fit over a batch that is SHARDED ACROSS RANKS (one process per GPU).  The host all-reduces
+ * (SUM) the small buffers between the calls; every rank ends with identical (HE, maxC):
+ *   sx_macenko_dfit_moments   local 20 fp64 raw moments            -> all-reduce
+ *   sx_macenko_dfit_begin     plane vectors from the global moments, starts the angle selection
+ *   repeat 4x: sx_macenko_dfit_histogram(stage)  local 2 x 256 u64 bins of the current radix round
+ *              -> all-reduce -> sx_macenko_dfit_advance(stage)     (stage 0: phi@1,phi@99; stage 1: C0@99,C1@99)
+ *   sx_macenko_dfit_result    copies HE (6 floats) and maxC (2 floats) out of the state             */
+size_t sx_macenko_dfit_state_bytes(void);
+int sx_macenko_dfit_moments(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
+                            double* moments_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int sx_macenko_dfit_begin(const double* moments_dev, void* state_dev, void* stream);
+int sx_macenko_dfit_histogram(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
+                              const void* state_dev, int stage, unsigned long long* hist_out_dev, void* stream);
+int sx_macenko_dfit_advance(void* state_dev, int stage, const unsigned long long* hist_dev, void* stream);
+int sx_macenko_dfit_result(const void* state_dev, float* he_out_dev, float* max_c_out_dev, void* stream);
+
 /* ---------------------------------------------------------------- Reinhard -----------------------
  * Replaces stainx_cuda_torch.reinhard (bindings.cpp:32) with the numerics of ReinhardTorch
  * (torch_backend.py:304-355): LAB statistics pooled over the whole batch, unbiased std. */
@@ -85,6 +101,15 @@ int sx_reinhard_fit(const void* images_dev, int dtype, int64_t n_tiles, int64_t 
 int sx_reinhard_transform(const void* images_dev, void* out_dev, int dtype, int64_t n_tiles, int64_t height,
                           int64_t width, const float* ref_mean_dev, const float* ref_std_dev,
                           void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Batch statistics pooled across ranks: sx_reinhard_sums writes 6 fp64 local sums (sum and sum of squares of
+ * LAB-128 per channel) -> all-reduce(SUM) -> sx_reinhard_apply normalises with the global sums over
+ * n_total_pixels = pixels per channel over all ranks. */
+int sx_reinhard_sums(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
+                     double* sums_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int sx_reinhard_apply(const void* images_dev, void* out_dev, int dtype, int64_t n_tiles, int64_t height,
+                      int64_t width, const double* sums_dev, double n_total_pixels, const float* ref_mean_dev,
+                      const float* ref_std_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- Histogram matching -------------
  * Replaces stainx_cuda_torch.histogram_matching (bindings.cpp:31) with the numerics of
@@ -98,6 +123,15 @@ int sx_hm_fit(const void* images_dev, int dtype, int64_t n_tiles, int64_t height
 int sx_hm_transform(const void* images_dev, void* out_dev, int dtype, int64_t n_tiles, int64_t height,
                     int64_t width, int channels_last, const float* ref_hist_dev, void* workspace_dev,
                     size_t workspace_bytes, void* stream);
+
+/* Source histogram pooled across ranks: sx_hm_counts writes the local 3 x 256 u64 counts -> all-reduce(SUM)
+ * -> sx_hm_apply builds the LUT from the global counts (n_total_pixels per channel over all ranks). */
+int sx_hm_counts(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
+                 int channels_last, unsigned long long* counts_out_dev, void* workspace_dev,
+                 size_t workspace_bytes, void* stream);
+int sx_hm_apply(const void* images_dev, void* out_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
+                int channels_last, const unsigned long long* counts_dev, double n_total_pixels,
+                const float* ref_hist_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

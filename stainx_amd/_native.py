@@ -33,7 +33,17 @@ SIGNATURES = {
     "sx_macenko_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _uint, _vp, _sz, _vp]),
     "sx_macenko_fit": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sx_macenko_tile_params": (_int, [_vp, _i64, _vp, _vp]),
+    "sx_macenko_dfit_state_bytes": (_sz, []),
+    "sx_macenko_dfit_moments": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "sx_macenko_dfit_begin": (_int, [_vp, _vp, _vp]),
+    "sx_macenko_dfit_histogram": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _int, _vp, _vp]),
+    "sx_macenko_dfit_advance": (_int, [_vp, _int, _vp, _vp]),
+    "sx_macenko_dfit_result": (_int, [_vp, _vp, _vp, _vp]),
     "sx_reinhard_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "sx_reinhard_sums": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "sx_reinhard_apply": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _c.c_double, _vp, _vp, _vp, _sz, _vp]),
+    "sx_hm_counts": (_int, [_vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
+    "sx_hm_apply": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _int, _vp, _c.c_double, _vp, _vp, _sz, _vp]),
     "sx_reinhard_fit": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sx_reinhard_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sx_hm_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -112,6 +112,53 @@ class MacenkoHIP(TorchHIPBackendBase):
     # name kept so code written against the reference's torch class keeps working
     compute_reference_stain_matrix_torch = compute_reference_stain_matrix
 
+    # ---- staged pooled fit for a batch sharded across ranks (see stainx_amd/distributed.py) ----------
+    def dfit_moments(self, images: torch.Tensor) -> torch.Tensor:
+        images = images.to(self.device)
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"Macenko fit expects NCHW with C=3, got shape {tuple(images.shape)}")
+        images = images.contiguous()
+        n, _, h, w = images.shape
+        mom = torch.empty(20, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_macenko_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_macenko_dfit_moments(images.data_ptr(), _dtype_code(images), n, h, w, mom.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_dfit_moments")
+        return mom
+
+    def dfit_begin(self, moments: torch.Tensor) -> torch.Tensor:
+        state = torch.zeros(self._lib.sx_macenko_dfit_state_bytes(), dtype=torch.uint8, device=self.device)
+        moments = moments.to(self.device, torch.float64).contiguous()
+        with torch.cuda.device(self.device):
+            rc = self._lib.sx_macenko_dfit_begin(moments.data_ptr(), state.data_ptr(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_dfit_begin")
+        return state
+
+    def dfit_histogram(self, images: torch.Tensor, state: torch.Tensor, stage: int) -> torch.Tensor:
+        images = images.to(self.device).contiguous()
+        n, _, h, w = images.shape
+        hist = torch.empty((2, 256), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.sx_macenko_dfit_histogram(images.data_ptr(), _dtype_code(images), n, h, w, state.data_ptr(), int(stage), hist.data_ptr(),
+                                                     _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_dfit_histogram")
+        return hist
+
+    def dfit_advance(self, state: torch.Tensor, stage: int, hist: torch.Tensor) -> None:
+        hist = hist.to(self.device, torch.int64).contiguous()
+        with torch.cuda.device(self.device):
+            rc = self._lib.sx_macenko_dfit_advance(state.data_ptr(), int(stage), hist.data_ptr(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_dfit_advance")
+
+    def dfit_result(self, state: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
+        max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.sx_macenko_dfit_result(state.data_ptr(), he.data_ptr(), max_c.data_ptr(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_dfit_result")
+        return he, max_c
+
     def tile_params(self, n_groups: int) -> dict[str, torch.Tensor]:
         """Intermediates of the last transform (per tile) or fit (one pooled group); used by tests."""
         if self.last_workspace is None:
@@ -166,6 +213,37 @@ class ReinhardHIP(TorchHIPBackendBase):
             rc = self._lib.sx_reinhard_transform(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(),
                                                  std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_reinhard_transform")
+        return out
+
+
+    # ---- batch statistics pooled across ranks (see stainx_amd/distributed.py) --------------------------
+    def local_sums(self, images: torch.Tensor) -> torch.Tensor:
+        """6 fp64 values: per channel sum and sum of squares of (LAB - 128) over this rank's pixels."""
+        images = images.to(self.device)
+        self._check(images)
+        images = images.contiguous()
+        n, _, h, w = images.shape
+        sums = torch.empty(6, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_reinhard_sums(images.data_ptr(), _dtype_code(images), n, h, w, sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _native.stream_ptr(self.device))
+        _native.check(rc, "sx_reinhard_sums")
+        return sums
+
+    def apply_with_sums(self, images: torch.Tensor, sums: torch.Tensor, n_total_pixels: int, reference_mean: torch.Tensor, reference_std: torch.Tensor) -> torch.Tensor:
+        images = images.to(self.device)
+        self._check(images)
+        images = images.contiguous()
+        mean, std = self._f32(reference_mean).flatten(), self._f32(reference_std).flatten()
+        sums = sums.to(self.device, torch.float64).contiguous()
+        n, _, h, w = images.shape
+        out = torch.empty_like(images)
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_reinhard_apply(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, sums.data_ptr(), float(n_total_pixels),
+                                             mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_reinhard_apply")
         return out
 
 
@@ -235,6 +313,32 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
             rc = self._lib.sx_hm_transform(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, int(last), ref.data_ptr(),
                                            ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_hm_transform")
+        self.last_workspace = ws
+        return out
+
+    # ---- source histogram pooled across ranks (see stainx_amd/distributed.py) --------------------------
+    def local_counts(self, images: torch.Tensor) -> torch.Tensor:
+        images = images.to(self.device).contiguous()
+        n, h, w, last = self._dims(images)
+        counts = torch.empty((3, 256), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_hm_counts(images.data_ptr(), _dtype_code(images), n, h, w, int(last), counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        _native.stream_ptr(self.device))
+        _native.check(rc, "sx_hm_counts")
+        return counts
+
+    def apply_with_counts(self, images: torch.Tensor, counts: torch.Tensor, n_total_pixels: int, reference_histogram) -> torch.Tensor:
+        images = images.to(self.device).contiguous()
+        n, h, w, last = self._dims(images)
+        ref = self._stack_reference(reference_histogram, 3)
+        counts = counts.to(self.device, torch.int64).contiguous()
+        out = torch.empty_like(images)
+        with torch.cuda.device(self.device):
+            ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
+            rc = self._lib.sx_hm_apply(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, int(last), counts.data_ptr(), float(n_total_pixels),
+                                       ref.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_hm_apply")
         self.last_workspace = ws
         return out
 

@@ -27,6 +27,7 @@ struct alignas(256) Tables {
     uint32_t counts[3][kBins];      // pooled integer histogram of the source batch
     float lut[3][kBins];            // float LUT (torch_backend.py:276-281)
     uint64_t typed_lut[3][kBins];   // LUT already converted to the output element (low bytes)
+    unsigned long long counts64[3][kBins];   // the histogram the LUT is built from (local, or all-reduced over ranks)
 };
 
 struct Layout {
@@ -105,9 +106,14 @@ template <typename O> __device__ __forceinline__ uint64_t pack_elem(O v) {
     return bits;
 }
 
+__global__ void widen_kernel(const uint32_t* __restrict__ counts, unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * kBins) out[i] = counts[i];
+}
+
 // One workgroup of 256 threads per channel.  InT decides the range rules of the output (:288-298).
 template <typename T>
-__global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, const float* __restrict__ ref_hist, double num_pixels) {
+__global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, const unsigned long long* __restrict__ counts, const float* __restrict__ ref_hist, double num_pixels) {
     const int c = blockIdx.x, t = threadIdx.x;
     __shared__ float src_cdf[kBins], ref_cdf[kBins];
     __shared__ float ref_total_s;
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, co
         const float denom = (float)(num_pixels + 1e-8);
         double run = 0.0;
         for (int b = 0; b < kBins; ++b) {
-            run += (double)((float)tab->counts[c][b] / denom);
+            run += (double)((float)counts[c * kBins + b] / denom);
             src_cdf[b] = (float)run;
         }
     } else if (t == 64) {
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const T* __restrict__ i
 static size_t workspace_bytes() { return sizeof(Tables); }
 
 template <typename T>
-static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, void* ws, hipStream_t stream) {
+static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, unsigned long long* counts_out, const unsigned long long* counts_in, double n_total, void* ws, hipStream_t stream) {
     Layout lay{n, h * w, channels_last};
     Tables* tab = static_cast<Tables*>(ws);
     const T* in = static_cast<const T*>(images);
@@ -201,16 +207,25 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
                      (channels_last ? (total % V == 0) : (lay.pixels % V == 0));
     const int64_t per_block = (int64_t)kThreads * (vec ? V : 1) * 4;
     const unsigned grid = (unsigned)std::min<int64_t>((total + per_block - 1) / per_block, 256 * 8);
-    if (hipMemsetAsync(tab->counts, 0, sizeof(tab->counts), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
-    if (vec)
-        hipLaunchKernelGGL((histogram_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
-    else
-        hipLaunchKernelGGL((histogram_kernel<T, false>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
-    if (hist_out) {
-        hipLaunchKernelGGL(normalise_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], hist_out);
-        return check_launch("histogram fit");
+    const unsigned long long* lut_counts = counts_in;
+    double lut_pixels = n_total;
+    if (!counts_in) {
+        if (hipMemsetAsync(tab->counts, 0, sizeof(tab->counts), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
+        if (vec)
+            hipLaunchKernelGGL((histogram_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
+        else
+            hipLaunchKernelGGL((histogram_kernel<T, false>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
+        if (hist_out) {
+            hipLaunchKernelGGL(normalise_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], hist_out);
+            return check_launch("histogram fit");
+        }
+        unsigned long long* wide = counts_out ? counts_out : &tab->counts64[0][0];
+        hipLaunchKernelGGL(widen_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], wide);
+        if (counts_out) return check_launch("histogram counts");
+        lut_counts = wide;
+        lut_pixels = (double)(n * h * w);
     }
-    hipLaunchKernelGGL((lut_kernel<T>), dim3(3), dim3(kBins), 0, stream, tab, ref_hist, (double)(n * h * w));
+    hipLaunchKernelGGL((lut_kernel<T>), dim3(3), dim3(kBins), 0, stream, tab, lut_counts, ref_hist, lut_pixels);
     if (vec)
         hipLaunchKernelGGL((apply_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, static_cast<T*>(out), lay, tab);
     else
@@ -218,18 +233,18 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
     return check_launch("histogram transform");
 }
 
-static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, void* ws, size_t ws_bytes, void* stream_ptr) {
+static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, unsigned long long* counts_out, const unsigned long long* counts_in, double n_total, void* ws, size_t ws_bytes, void* stream_ptr) {
     if (!images) return fail(SX_ERR_BAD_ARG, "images pointer is null");
     if (n <= 0 || h <= 0 || w <= 0) return fail(SX_ERR_BAD_ARG, "images must have positive sizes, got N=%lld H=%lld W=%lld", (long long)n, (long long)h, (long long)w);
     if (!ws || ws_bytes < workspace_bytes()) return fail(SX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", workspace_bytes(), ws_bytes);
     if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(SX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
-        case SX_U8: return run<uint8_t>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
-        case SX_F16: return run<__half>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
-        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
-        case SX_F32: return run<float>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
-        case SX_F64: return run<double>(images, out, n, h, w, channels_last, ref_hist, hist_out, ws, stream);
+        case SX_U8: return run<uint8_t>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
+        case SX_F16: return run<__half>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
+        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
+        case SX_F32: return run<float>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
+        case SX_F64: return run<double>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
         default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
     }
 }
@@ -246,10 +261,22 @@ extern "C" size_t sx_hm_workspace_bytes(int64_t n, int64_t h, int64_t w) {
 
 extern "C" int sx_hm_fit(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, float* hist_out, void* ws, size_t ws_bytes, void* stream) {
     if (!hist_out) return fail(SX_ERR_BAD_ARG, "hist_out pointer is null");
-    return histmatch::dispatch(images, nullptr, dtype, n, h, w, channels_last, nullptr, hist_out, ws, ws_bytes, stream);
+    return histmatch::dispatch(images, nullptr, dtype, n, h, w, channels_last, nullptr, hist_out, nullptr, nullptr, 0.0, ws, ws_bytes, stream);
 }
 
 extern "C" int sx_hm_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, void* ws, size_t ws_bytes, void* stream) {
     if (!out || !ref_hist) return fail(SX_ERR_BAD_ARG, "out / ref_hist pointer is null");
-    return histmatch::dispatch(images, out, dtype, n, h, w, channels_last, ref_hist, nullptr, ws, ws_bytes, stream);
+    return histmatch::dispatch(images, out, dtype, n, h, w, channels_last, ref_hist, nullptr, nullptr, nullptr, 0.0, ws, ws_bytes, stream);
+}
+
+// Source histogram pooled ACROSS RANKS: local integer counts out (3 x 256 u64), all-reduce on the host side, apply with the global counts.
+extern "C" int sx_hm_counts(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, unsigned long long* counts_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!counts_out) return fail(SX_ERR_BAD_ARG, "counts_out pointer is null");
+    return histmatch::dispatch(images, nullptr, dtype, n, h, w, channels_last, nullptr, nullptr, counts_out, nullptr, 0.0, ws, ws_bytes, stream);
+}
+
+extern "C" int sx_hm_apply(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const unsigned long long* counts, double n_total_pixels, const float* ref_hist, void* ws, size_t ws_bytes, void* stream) {
+    if (!out || !counts || !ref_hist) return fail(SX_ERR_BAD_ARG, "out / counts / ref_hist pointer is null");
+    if (!(n_total_pixels >= 1.0)) return fail(SX_ERR_BAD_ARG, "n_total_pixels must be >= 1");
+    return histmatch::dispatch(images, out, dtype, n, h, w, channels_last, ref_hist, nullptr, nullptr, counts, n_total_pixels, ws, ws_bytes, stream);
 }

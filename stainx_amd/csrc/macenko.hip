@@ -249,6 +249,59 @@ __device__ void jacobi_eigh3(const double a_in[9], double w[3], double q[9]) {
 }
 #undef SX_JACOBI_ROTATE
 
+// Angle percentiles -> extreme stain vectors -> HE_source (H before E) -> its (2,3) pseudo-inverse.
+__device__ void stain_vectors_and_pinv(const float* vecs, float phi_lo, float phi_hi, float* he_out, float* pinv_out) {
+    const float cl = cosf(phi_lo), sl = sinf(phi_lo), ch = cosf(phi_hi), sh = sinf(phi_hi);   // torch_backend.py:427-430
+    float vmin[3], vmax[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        vmin[r] = fmaf(vecs[r * 2 + 1], sl, vecs[r * 2] * cl);                                   // :436
+        vmax[r] = fmaf(vecs[r * 2 + 1], sh, vecs[r * 2] * ch);                                   // :437
+    }
+    const bool min_first = vmin[0] > vmax[0];                                                    // :439
+    float he[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        he[r * 2] = min_first ? vmin[r] : vmax[r];
+        he[r * 2 + 1] = min_first ? vmax[r] : vmin[r];
+    }
+    // pseudo-inverse (2,3) of HE (3,2) in fp64 through the eigen-decomposition of HE^T HE, dropping a
+    // singular value below 3*eps_f32 of the largest (rank rule of lstsq(rcond=None), torch_backend.py:379)
+    const double a = (double)he[0] * he[0] + (double)he[2] * he[2] + (double)he[4] * he[4];
+    const double b = (double)he[0] * he[1] + (double)he[2] * he[3] + (double)he[4] * he[5];
+    const double d = (double)he[1] * he[1] + (double)he[3] * he[3] + (double)he[5] * he[5];
+    const double tr = a + d, df = a - d;
+    const double disc = sqrt(df * df + 4.0 * b * b);
+    const double l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
+    double e1x, e1y;                                   // unit eigenvector of l1
+    if (fabs(b) > 0.0) {
+        e1x = l1 - d;
+        e1y = b;
+    } else if (a >= d) {
+        e1x = 1.0;
+        e1y = 0.0;
+    } else {
+        e1x = 0.0;
+        e1y = 1.0;
+    }
+    const double nrm = sqrt(e1x * e1x + e1y * e1y);
+    e1x /= nrm;
+    e1y /= nrm;
+    const double e2x = -e1y, e2y = e1x;
+    const double rc = 3.0 * 1.1920928955078125e-07;
+    const double i1 = l1 > 0.0 ? 1.0 / l1 : 0.0;
+    const double i2 = (l2 > 0.0 && sqrt(l2) > rc * sqrt(l1)) ? 1.0 / l2 : 0.0;
+    // (HE^T HE)^+ = i1 e1 e1^T + i2 e2 e2^T
+    const double g00 = i1 * e1x * e1x + i2 * e2x * e2x, g01 = i1 * e1x * e1y + i2 * e2x * e2y, g11 = i1 * e1y * e1y + i2 * e2y * e2y;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pinv_out[c] = (float)(g00 * he[c * 2] + g01 * he[c * 2 + 1]);
+        pinv_out[3 + c] = (float)(g01 * he[c * 2] + g11 * he[c * 2 + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) he_out[i] = he[i];
+}
+
 // k = round(0.01*q*(n-1)), half to even, evaluated in double like the Python expression at
 // torch_backend.py:364 (0-based rank).
 __device__ __forceinline__ unsigned long long nearest_rank_index(double q, unsigned long long n) {
@@ -496,6 +549,38 @@ __device__ void sample_brackets(const uint32_t (&keys)[NSETS][kSamplePerThread],
     }
 }
 
+// Raw moments -> unbiased covariance (torch_backend.py:395-397) -> plane vectors, columns [1,2] of eigh
+// (torch_backend.py:415), sign convention: positive component sum.  mom[0..9] masked set, mom[10..19] all pixels;
+// fewer than 3 masked pixels -> all pixels when allow_fallback (torch_backend.py:409-410).
+__device__ void plane_from_moments(const double* mom, bool allow_fallback, double cov[9], float vecs[6], bool& use_all, unsigned long long& n_sel) {
+    use_all = allow_fallback && mom[0] < 3.0;
+    const double* a = use_all ? mom + 10 : mom;
+    const double cnt = a[0];
+    if (cnt > 1.0) {
+        const double m0 = a[1] / cnt, m1 = a[2] / cnt, m2 = a[3] / cnt, d = cnt - 1.0;
+        cov[0] = (a[4] - a[1] * m0) / d;
+        cov[1] = cov[3] = (a[5] - a[1] * m1) / d;
+        cov[2] = cov[6] = (a[6] - a[1] * m2) / d;
+        cov[4] = (a[7] - a[2] * m1) / d;
+        cov[5] = cov[7] = (a[8] - a[2] * m2) / d;
+        cov[8] = (a[9] - a[3] * m2) / d;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cov[i] = 0.0;
+    }
+    double w[3], q[9];
+    jacobi_eigh3(cov, w, q);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int src = c + 1;
+        const double sum = q[0 * 3 + src] + q[1 * 3 + src] + q[2 * 3 + src];
+        const double sgn = sum < 0.0 ? -1.0 : 1.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) vecs[r * 2 + c] = (float)(sgn * q[r * 3 + src]);
+    }
+    n_sel = (unsigned long long)cnt;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-tile kernel A: moments -> covariance -> plane vectors; angle brackets from the sample
 // ------------------------------------------------------------------------------------------------
@@ -532,32 +617,11 @@ __global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restric
 
     SX_STAMP(st, 1);
     if (threadIdx.x == 0) {
-        const bool use_all = allow_fallback && mom[0] < 3.0;            // torch_backend.py:409-410
-        const double* a = use_all ? mom + 10 : mom;
-        const double cnt = a[0];
         double cov[9];
-        if (cnt > 1.0) {                                                // torch_backend.py:395-397
-            const double m0 = a[1] / cnt, m1 = a[2] / cnt, m2 = a[3] / cnt, d = cnt - 1.0;
-            cov[0] = (a[4] - a[1] * m0) / d;
-            cov[1] = cov[3] = (a[5] - a[1] * m1) / d;
-            cov[2] = cov[6] = (a[6] - a[1] * m2) / d;
-            cov[4] = (a[7] - a[2] * m1) / d;
-            cov[5] = cov[7] = (a[8] - a[2] * m2) / d;
-            cov[8] = (a[9] - a[3] * m2) / d;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) cov[i] = 0.0;
-        }
-        double w[3], q[9];
-        jacobi_eigh3(cov, w, q);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {                                   // columns [1,2] of eigh (torch_backend.py:415)
-            const int src = c + 1;
-            const double sum = q[0 * 3 + src] + q[1 * 3 + src] + q[2 * 3 + src];
-            const double sgn = sum < 0.0 ? -1.0 : 1.0;                  // sign convention: positive component sum
-#pragma unroll
-            for (int r = 0; r < 3; ++r) v_s[r * 2 + c] = (float)(sgn * q[r * 3 + src]);
-        }
+        bool use_all;
+        unsigned long long n_sel_local;
+        plane_from_moments(mom, allow_fallback != 0, cov, v_s, use_all, n_sel_local);
+        const double cnt = (double)n_sel_local;
         use_all_s = use_all ? 1 : 0;
         n_sel_s = (unsigned long long)cnt;
 #pragma unroll
@@ -796,53 +860,8 @@ __global__ __launch_bounds__(kGroupThreads) void stain_kernel(const T* __restric
 
     if (threadIdx.x == 0) {
         const float phi_lo = key_float(phi_key[0]), phi_hi = key_float(phi_key[1]);
-        const float cl = cosf(phi_lo), sl = sinf(phi_lo), ch = cosf(phi_hi), sh = sinf(phi_hi);   // torch_backend.py:427-430
-        float vmin[3], vmax[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            vmin[r] = fmaf(st.vecs[r * 2 + 1], sl, st.vecs[r * 2] * cl);                             // :436
-            vmax[r] = fmaf(st.vecs[r * 2 + 1], sh, st.vecs[r * 2] * ch);                             // :437
-        }
-        const bool min_first = vmin[0] > vmax[0];                                                    // :439
         float he[6];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            he[r * 2] = min_first ? vmin[r] : vmax[r];
-            he[r * 2 + 1] = min_first ? vmax[r] : vmin[r];
-        }
-        // pseudo-inverse (2,3) of HE (3,2) in fp64 through the eigen-decomposition of HE^T HE, dropping a
-        // singular value below 3*eps_f32 of the largest (rank rule of lstsq(rcond=None), torch_backend.py:379)
-        const double a = (double)he[0] * he[0] + (double)he[2] * he[2] + (double)he[4] * he[4];
-        const double b = (double)he[0] * he[1] + (double)he[2] * he[3] + (double)he[4] * he[5];
-        const double d = (double)he[1] * he[1] + (double)he[3] * he[3] + (double)he[5] * he[5];
-        const double tr = a + d, df = a - d;
-        const double disc = sqrt(df * df + 4.0 * b * b);
-        const double l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
-        double e1x, e1y;                                   // unit eigenvector of l1
-        if (fabs(b) > 0.0) {
-            e1x = l1 - d;
-            e1y = b;
-        } else if (a >= d) {
-            e1x = 1.0;
-            e1y = 0.0;
-        } else {
-            e1x = 0.0;
-            e1y = 1.0;
-        }
-        const double nrm = sqrt(e1x * e1x + e1y * e1y);
-        e1x /= nrm;
-        e1y /= nrm;
-        const double e2x = -e1y, e2y = e1x;
-        const double rc = 3.0 * 1.1920928955078125e-07;
-        const double i1 = l1 > 0.0 ? 1.0 / l1 : 0.0;
-        const double i2 = (l2 > 0.0 && sqrt(l2) > rc * sqrt(l1)) ? 1.0 / l2 : 0.0;
-        // (HE^T HE)^+ = i1 e1 e1^T + i2 e2 e2^T
-        const double g00 = i1 * e1x * e1x + i2 * e2x * e2x, g01 = i1 * e1x * e1y + i2 * e2x * e2y, g11 = i1 * e1y * e1y + i2 * e2y * e2y;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            pinv_s[c] = (float)(g00 * he[c * 2] + g01 * he[c * 2 + 1]);
-            pinv_s[3 + c] = (float)(g01 * he[c * 2] + g11 * he[c * 2 + 1]);
-        }
+        stain_vectors_and_pinv(st.vecs, phi_lo, phi_hi, he, pinv_s);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             st.he[i] = he[i];
@@ -985,6 +1004,132 @@ __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// distributed pooled fit: the batch is sharded over ranks, every reduction stage is one
+// small all-reduce done by the host between these kernels.  Order statistics use a plain 4-round byte
+// radix select whose 256-bin histograms are integer sums over ranks => the same (HE, maxC) bits on
+// every rank, whatever the sharding.
+// ------------------------------------------------------------------------------------------------
+struct alignas(256) DFitState {
+    double mom[kMoments];
+    float vecs[6], he[6], pinv[6];
+    float phi[2], max_c[2];
+    unsigned long long n_sel, n_all;
+    unsigned long long rank[kSlots];
+    uint32_t prefix[kSlots], mask[kSlots];
+    int round[2];
+};
+
+__global__ void dfit_reduce_partials_kernel(const double* __restrict__ partial, int64_t nblk, double* __restrict__ moments) {
+    const int k = threadIdx.x;
+    if (k >= kMoments) return;
+    double s = 0.0;
+    for (int64_t b = 0; b < nblk; ++b) s += partial[b * kMoments + k];
+    moments[k] = s;
+}
+
+__global__ void dfit_begin_kernel(const double* __restrict__ moments, DFitState* __restrict__ st) {
+    if (threadIdx.x != 0) return;
+    for (int k = 0; k < kMoments; ++k) st->mom[k] = moments[k];
+    double cov[9];
+    bool use_all;
+    unsigned long long n_sel;
+    plane_from_moments(st->mom, false, cov, st->vecs, use_all, n_sel);
+    st->n_sel = n_sel;
+    st->n_all = (unsigned long long)st->mom[10];
+    st->rank[0] = nearest_rank_index(1.0, n_sel);
+    st->rank[1] = nearest_rank_index(99.0, n_sel);
+    for (int s = 0; s < kSlots; ++s) st->prefix[s] = st->mask[s] = 0;
+    st->round[0] = st->round[1] = 0;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kStreamThreads) void dfit_histogram_kernel(const T* __restrict__ images, Geometry g, const DFitState* __restrict__ st, int stage, unsigned long long* __restrict__ hist) {
+    const int64_t tile = blockIdx.x / g.blocks_per_tile;
+    const int chunk_id = blockIdx.x % g.blocks_per_tile;
+    const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
+    const T* img = images + tile * 3 * g.pixels;
+    __shared__ uint32_t local[2][256];
+    for (int i = threadIdx.x; i < 512; i += kStreamThreads) (&local[0][0])[i] = 0;
+    __syncthreads();
+    const int s0 = stage * 2;
+    float coef[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) coef[i] = stage ? st->pinv[i] : st->vecs[i];
+    const int shift = 24 - 8 * st->round[stage];
+    const uint32_t pa = st->prefix[s0], ma = st->mask[s0], pb = st->prefix[s0 + 1], mb = st->mask[s0 + 1];
+    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
+        float u[3][V];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float od[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
+            uint32_t ka, kb;
+            if (stage) {
+                float c0, c1;
+                concentration(od, coef, c0, c1);
+                ka = float_key(c0);
+                kb = float_key(c1);
+            } else {
+                if (!od_selected(od, false)) continue;
+                ka = kb = angle_key(od, coef);
+            }
+            if (((ka ^ pa) & ma) == 0) atomicAdd(&local[0][(ka >> shift) & 255u], 1u);
+            if (((kb ^ pb) & mb) == 0) atomicAdd(&local[1][(kb >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += kStreamThreads) {
+        const uint32_t v = (&local[0][0])[i];
+        if (v) atomicAdd(&hist[i], (unsigned long long)v);
+    }
+}
+
+__global__ __launch_bounds__(128) void dfit_advance_kernel(DFitState* __restrict__ st, int stage, const unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t bins[2][256];
+    __shared__ unsigned long long carry[2][256];
+    const int s0 = stage * 2;
+    // histograms can exceed 2^32 per bin in principle: scan in 64 bit with one thread per slot
+    if (threadIdx.x < 2) {
+        const int j = threadIdx.x;
+        unsigned long long r = st->rank[s0 + j], cum = 0;
+        int d = 0;
+        for (; d < 255; ++d) {
+            const unsigned long long h = hist[j * 256 + d];
+            if (cum + h > r) break;
+            cum += h;
+        }
+        const int shift = 24 - 8 * st->round[stage];
+        st->prefix[s0 + j] |= (uint32_t)d << shift;
+        st->mask[s0 + j] |= 0xFFu << shift;
+        st->rank[s0 + j] = r - cum;
+    }
+    (void)bins;
+    (void)carry;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    st->round[stage] += 1;
+    if (st->round[stage] < 4) return;
+    if (stage == 0) {
+        const float phi_lo = key_float(st->prefix[0]), phi_hi = key_float(st->prefix[1]);
+        st->phi[0] = phi_lo;
+        st->phi[1] = phi_hi;
+        stain_vectors_and_pinv(st->vecs, phi_lo, phi_hi, st->he, st->pinv);
+        st->rank[2] = st->rank[3] = nearest_rank_index(99.0, st->n_all);
+    } else {
+        st->max_c[0] = key_float(st->prefix[2]);
+        st->max_c[1] = key_float(st->prefix[3]);
+    }
+}
+
+__global__ void dfit_result_kernel(const DFitState* __restrict__ st, float* __restrict__ he_out, float* __restrict__ max_c_out) {
+    if (threadIdx.x < 6) he_out[threadIdx.x] = st->he[threadIdx.x];
+    if (threadIdx.x < 2) max_c_out[threadIdx.x] = st->max_c[threadIdx.x];
+}
+
 __global__ void export_params_kernel(const GroupState* __restrict__ state, int64_t n_groups, float* __restrict__ out) {
     const int64_t gidx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (gidx >= n_groups) return;
@@ -1061,6 +1206,38 @@ static int fit_typed(const void* images, const Geometry& g0, const Workspace& ws
                : run_estimate<T, 1>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream);
 }
 
+
+// ---- distributed pooled fit: staged entry points (host does the all-reduces in between) -----------
+template <typename T>
+static int dfit_moments_typed(const void* images, const Geometry& g0, const Workspace& ws, double* moments, hipStream_t stream) {
+    Geometry g = g0;
+    const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4);
+    g.chunk = kStreamThreads * 4 * kIters;
+    const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
+    const T* in = static_cast<const T*>(images);
+    if (vec)
+        hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws.partial);
+    else
+        hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws.partial);
+    hipLaunchKernelGGL(dfit_reduce_partials_kernel, dim3(1), dim3(64), 0, stream, ws.partial, (int64_t)grid, moments);
+    return check_launch("macenko dfit moments");
+}
+
+template <typename T>
+static int dfit_histogram_typed(const void* images, const Geometry& g0, const DFitState* st, int stage, unsigned long long* hist, hipStream_t stream) {
+    Geometry g = g0;
+    const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4);
+    g.chunk = kStreamThreads * 4 * kIters;
+    const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
+    const T* in = static_cast<const T*>(images);
+    if (hipMemsetAsync(hist, 0, 512 * sizeof(unsigned long long), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
+    if (vec)
+        hipLaunchKernelGGL((dfit_histogram_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, stage, hist);
+    else
+        hipLaunchKernelGGL((dfit_histogram_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, stage, hist);
+    return check_launch("macenko dfit histogram");
+}
+
 }  // namespace macenko
 }  // namespace sx
 
@@ -1122,4 +1299,57 @@ extern "C" int sx_macenko_tile_params(const void* ws_ptr, int64_t n_groups, floa
     const unsigned grid = (unsigned)((n_groups + 63) / 64);
     hipLaunchKernelGGL(export_params_kernel, dim3(grid), dim3(64), 0, stream, static_cast<const GroupState*>(ws_ptr), n_groups, params_out);
     return check_launch("macenko export_params");
+}
+
+extern "C" size_t sx_macenko_dfit_state_bytes(void) { return sizeof(DFitState); }
+
+extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n, int64_t h, int64_t w, double* moments_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
+    if (rc != SX_OK) return rc;
+    if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1};
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    switch (dtype) {
+        case SX_U8: return dfit_moments_typed<uint8_t>(images, g, ws, moments_out, stream);
+        case SX_F16: return dfit_moments_typed<__half>(images, g, ws, moments_out, stream);
+        case SX_BF16: return dfit_moments_typed<__hip_bfloat16>(images, g, ws, moments_out, stream);
+        case SX_F32: return dfit_moments_typed<float>(images, g, ws, moments_out, stream);
+        case SX_F64: return dfit_moments_typed<double>(images, g, ws, moments_out, stream);
+        default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    }
+}
+
+extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* stream_ptr) {
+    if (!moments || !state) return fail(SX_ERR_BAD_ARG, "moments / state pointer is null");
+    hipLaunchKernelGGL(dfit_begin_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_ptr), moments, static_cast<DFitState*>(state));
+    return check_launch("macenko dfit begin");
+}
+
+extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
+    if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
+    if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1};
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    const DFitState* st = static_cast<const DFitState*>(state);
+    switch (dtype) {
+        case SX_U8: return dfit_histogram_typed<uint8_t>(images, g, st, stage, hist_out, stream);
+        case SX_F16: return dfit_histogram_typed<__half>(images, g, st, stage, hist_out, stream);
+        case SX_BF16: return dfit_histogram_typed<__hip_bfloat16>(images, g, st, stage, hist_out, stream);
+        case SX_F32: return dfit_histogram_typed<float>(images, g, st, stage, hist_out, stream);
+        case SX_F64: return dfit_histogram_typed<double>(images, g, st, stage, hist_out, stream);
+        default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    }
+}
+
+extern "C" int sx_macenko_dfit_advance(void* state, int stage, const unsigned long long* hist, void* stream_ptr) {
+    if (!state || !hist || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad argument to sx_macenko_dfit_advance");
+    hipLaunchKernelGGL(dfit_advance_kernel, dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream_ptr), static_cast<DFitState*>(state), stage, hist);
+    return check_launch("macenko dfit advance");
+}
+
+extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* max_c_out, void* stream_ptr) {
+    if (!state || !he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "bad argument to sx_macenko_dfit_result");
+    hipLaunchKernelGGL(dfit_result_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_ptr), static_cast<const DFitState*>(state), he_out, max_c_out);
+    return check_launch("macenko dfit result");
 }

@@ -68,7 +68,7 @@ struct Geometry {
 };
 
 template <typename T, int V>
-__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, State* __restrict__ st, double* __restrict__ partial, float* __restrict__ mean_out, float* __restrict__ std_out) {
+__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, State* __restrict__ st, double* __restrict__ partial, float* __restrict__ mean_out, float* __restrict__ std_out, double* __restrict__ sums_out) {
     const int64_t tile = blockIdx.x / g.blocks_per_tile;
     const int chunk_id = blockIdx.x % g.blocks_per_tile;
     const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
         double s = 0.0;
         for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&partial[(int64_t)b * kSums + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         red[0][threadIdx.x] = s;
+        if (sums_out) sums_out[threadIdx.x] = s;     // raw shifted sums for a cross-rank all-reduce
     }
     __syncthreads();
     if (threadIdx.x < 3) {
@@ -195,19 +196,33 @@ static size_t workspace_bytes(int64_t n, int64_t pixels) { return align_up(sizeo
 
 __global__ void init_state_kernel(State* st) { st->arrivals = 0; }
 
+// mean / unbiased std from (possibly all-reduced) shifted sums over n pixels per channel
+__global__ void finalize_kernel(const double* __restrict__ sums, double n, State* __restrict__ st) {
+    const int c = threadIdx.x;
+    if (c >= 3) return;
+    const double m = sums[c] / n;
+    const double var = n > 1.0 ? (sums[3 + c] - sums[c] * m) / (n - 1.0) : __longlong_as_double(0x7ff8000000000000ll);
+    st->mean[c] = (float)(m + (double)lab_shift(c));
+    st->stdv[c] = (float)sqrt(fmax(var, 0.0));
+}
+
 template <typename T>
-static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, float* mean_out, float* std_out, void* ws, hipStream_t stream) {
+static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, float* mean_out, float* std_out, double* sums_out, const double* sums_in, double n_total, void* ws, hipStream_t stream) {
     Geometry g{n, h * w, blocks_for(h * w), kStreamThreads * 4 * kIters};
     State* st = static_cast<State*>(ws);
     double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + align_up(sizeof(State), 256));
     const bool vec = (g.pixels % 4 == 0) && (reinterpret_cast<uintptr_t>(images) % (sizeof(T) * 4) == 0) && (!out || reinterpret_cast<uintptr_t>(out) % (sizeof(T) * 4) == 0);
     const unsigned grid = (unsigned)(n * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
-    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, st);
-    if (vec)
-        hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, mean_out, std_out);
-    else
-        hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, mean_out, std_out);
+    if (sums_in) {            // statistics come from outside (all-reduced over ranks)
+        hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, sums_in, n_total, st);
+    } else {
+        hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, st);
+        if (vec)
+            hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, mean_out, std_out, sums_out);
+        else
+            hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, mean_out, std_out, sums_out);
+    }
     if (out) {
         if (vec)
             hipLaunchKernelGGL((apply_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, static_cast<T*>(out), g, st, ref_mean, ref_std);
@@ -217,7 +232,7 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, c
     return check_launch("reinhard");
 }
 
-static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* rm, const float* rs, float* mo, float* so, void* ws, size_t ws_bytes, void* stream_ptr) {
+static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* rm, const float* rs, float* mo, float* so, double* sums_out, const double* sums_in, double n_total, void* ws, size_t ws_bytes, void* stream_ptr) {
     if (!images) return fail(SX_ERR_BAD_ARG, "images pointer is null");
     if (n <= 0 || h <= 0 || w <= 0) return fail(SX_ERR_BAD_ARG, "images must be (N,3,H,W) with positive sizes");
     const size_t need = workspace_bytes(n, h * w);
@@ -225,11 +240,11 @@ static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t
     if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(SX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
-        case SX_U8: return run<uint8_t>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
-        case SX_F16: return run<__half>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
-        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
-        case SX_F32: return run<float>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
-        case SX_F64: return run<double>(images, out, n, h, w, rm, rs, mo, so, ws, stream);
+        case SX_U8: return run<uint8_t>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream);
+        case SX_F16: return run<__half>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream);
+        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream);
+        case SX_F32: return run<float>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream);
+        case SX_F64: return run<double>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream);
         default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
     }
 }
@@ -246,10 +261,22 @@ extern "C" size_t sx_reinhard_workspace_bytes(int64_t n, int64_t h, int64_t w) {
 
 extern "C" int sx_reinhard_fit(const void* images, int dtype, int64_t n, int64_t h, int64_t w, float* mean_out, float* std_out, void* ws, size_t ws_bytes, void* stream) {
     if (!mean_out || !std_out) return fail(SX_ERR_BAD_ARG, "mean_out / std_out pointer is null");
-    return reinhard::dispatch(images, nullptr, dtype, n, h, w, nullptr, nullptr, mean_out, std_out, ws, ws_bytes, stream);
+    return reinhard::dispatch(images, nullptr, dtype, n, h, w, nullptr, nullptr, mean_out, std_out, nullptr, nullptr, 0.0, ws, ws_bytes, stream);
 }
 
 extern "C" int sx_reinhard_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, void* ws, size_t ws_bytes, void* stream) {
     if (!out || !ref_mean || !ref_std) return fail(SX_ERR_BAD_ARG, "out / ref_mean / ref_std pointer is null");
-    return reinhard::dispatch(images, out, dtype, n, h, w, ref_mean, ref_std, nullptr, nullptr, ws, ws_bytes, stream);
+    return reinhard::dispatch(images, out, dtype, n, h, w, ref_mean, ref_std, nullptr, nullptr, nullptr, nullptr, 0.0, ws, ws_bytes, stream);
+}
+
+// Batch statistics pooled ACROSS RANKS: local shifted sums out, all-reduce on the host side, apply with the global sums.
+extern "C" int sx_reinhard_sums(const void* images, int dtype, int64_t n, int64_t h, int64_t w, double* sums_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!sums_out) return fail(SX_ERR_BAD_ARG, "sums_out pointer is null");
+    return reinhard::dispatch(images, nullptr, dtype, n, h, w, nullptr, nullptr, nullptr, nullptr, sums_out, nullptr, 0.0, ws, ws_bytes, stream);
+}
+
+extern "C" int sx_reinhard_apply(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const double* sums, double n_total_pixels, const float* ref_mean, const float* ref_std, void* ws, size_t ws_bytes, void* stream) {
+    if (!out || !sums || !ref_mean || !ref_std) return fail(SX_ERR_BAD_ARG, "out / sums / ref_mean / ref_std pointer is null");
+    if (!(n_total_pixels >= 1.0)) return fail(SX_ERR_BAD_ARG, "n_total_pixels must be >= 1");
+    return reinhard::dispatch(images, out, dtype, n, h, w, ref_mean, ref_std, nullptr, nullptr, nullptr, sums, n_total_pixels, ws, ws_bytes, stream);
 }

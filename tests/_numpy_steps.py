@@ -1,0 +1,135 @@
+"""Stand-in *steps* providers for stainx_amd.distributed built on numpy and the oracle (TEST CODE).
+
+They implement the same staged interface as the HIP backend classes so that the collective
+choreography of ``stainx_amd/distributed.py`` can run on CPU-only machines under gloo."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import stain_oracle as so
+
+
+def float_key(x: np.ndarray) -> np.ndarray:
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    return np.where(u >> 31 != 0, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def key_float(k: int) -> np.float32:
+    k = np.uint32(k)
+    u = (k & np.uint32(0x7FFFFFFF)) if (k >> 31) else ~k
+    return np.array([u], dtype=np.uint32).view(np.float32)[0]
+
+
+def nearest_rank_index(q: float, n: int) -> int:
+    return 0 if n == 0 else round(0.01 * q * (n - 1))
+
+
+class NumpyMacenkoSteps:
+    def _od_rows(self, images: torch.Tensor) -> np.ndarray:
+        od = so.optical_density(so.to_unit_float(images.numpy()))
+        return np.transpose(od, (1, 0, 2, 3)).reshape(3, -1).T          # (n,3)
+
+    def dfit_moments(self, images):
+        rows = self._od_rows(images).astype(np.float64)
+        keep = self._od_rows(images).min(axis=1) >= so.BETA
+
+        def raw(x):
+            return [x.shape[0], *x.sum(0), (x[:, 0] * x[:, 0]).sum(), (x[:, 0] * x[:, 1]).sum(), (x[:, 0] * x[:, 2]).sum(),
+                    (x[:, 1] * x[:, 1]).sum(), (x[:, 1] * x[:, 2]).sum(), (x[:, 2] * x[:, 2]).sum()]
+
+        return torch.tensor(raw(rows[keep]) + raw(rows), dtype=torch.float64)
+
+    def dfit_begin(self, moments):
+        a = moments.numpy()
+        cnt = a[0]
+        mean = a[1:4] / cnt
+        sxy = np.array([[a[4], a[5], a[6]], [a[5], a[7], a[8]], [a[6], a[8], a[9]]])
+        cov = (sxy - np.outer(a[1:4], mean)) / (cnt - 1)
+        _, vecs = np.linalg.eigh(cov)
+        vecs = vecs[:, [1, 2]]
+        vecs = vecs * np.where(vecs.sum(0) < 0, -1.0, 1.0)[None, :]
+        n_sel, n_all = int(cnt), int(a[10])
+        return {"vecs": vecs.astype(np.float32), "n_sel": n_sel, "n_all": n_all, "rank": [nearest_rank_index(1, n_sel), nearest_rank_index(99, n_sel), 0, 0],
+                "prefix": [0, 0, 0, 0], "mask": [0, 0, 0, 0], "round": [0, 0]}
+
+    def _keys(self, images, state, stage):
+        rows = self._od_rows(images)
+        if stage == 0:
+            kept = rows[rows.min(axis=1) >= so.BETA]
+            proj = (kept @ state["vecs"]).astype(np.float32)
+            k = float_key(np.arctan2(proj[:, 1], proj[:, 0]).astype(np.float32))
+            return k, k
+        conc = (state["pinv"] @ rows.T).astype(np.float32)
+        return float_key(conc[0]), float_key(conc[1])
+
+    def dfit_histogram(self, images, state, stage):
+        shift = 24 - 8 * state["round"][stage]
+        out = np.zeros((2, 256), dtype=np.int64)
+        for j, k in enumerate(self._keys(images, state, stage)):
+            s = stage * 2 + j
+            member = ((k ^ np.uint32(state["prefix"][s])) & np.uint32(state["mask"][s])) == 0
+            out[j] = np.bincount((k[member] >> np.uint32(shift)) & np.uint32(255), minlength=256)
+        return torch.from_numpy(out)
+
+    def dfit_advance(self, state, stage, hist):
+        h = hist.numpy()
+        shift = 24 - 8 * state["round"][stage]
+        for j in range(2):
+            s = stage * 2 + j
+            cum = np.cumsum(h[j])
+            d = int(np.searchsorted(cum, state["rank"][s], side="right"))
+            d = min(d, 255)
+            state["rank"][s] -= int(cum[d - 1]) if d > 0 else 0
+            state["prefix"][s] |= d << shift
+            state["mask"][s] |= 0xFF << shift
+        state["round"][stage] += 1
+        if state["round"][stage] < 4:
+            return
+        if stage == 0:
+            state["he"] = so.stain_vectors_from_angles(state["vecs"], key_float(state["prefix"][0]), key_float(state["prefix"][1]))
+            state["pinv"] = np.linalg.pinv(state["he"].astype(np.float64)).astype(np.float32)
+            state["rank"][2] = state["rank"][3] = nearest_rank_index(99, state["n_all"])
+        else:
+            state["max_c"] = np.array([key_float(state["prefix"][2]), key_float(state["prefix"][3])], dtype=np.float32)
+
+    def dfit_result(self, state):
+        return torch.from_numpy(state["he"].copy()), torch.from_numpy(state["max_c"].copy())
+
+
+class NumpyReinhardSteps:
+    def local_sums(self, images):
+        lab = so.rgb_to_lab(so.to_unit_float(images.numpy())).astype(np.float64) - 128.0
+        flat = np.transpose(lab, (1, 0, 2, 3)).reshape(3, -1)
+        return torch.from_numpy(np.concatenate([flat.sum(1), (flat * flat).sum(1)]))
+
+    def apply_with_sums(self, images, sums, n_total, ref_mean, ref_std):
+        s = sums.numpy()
+        mean = s[:3] / n_total
+        std = np.sqrt((s[3:] - s[:3] * mean) / (n_total - 1))
+        x = images.numpy()
+        lab = so.rgb_to_lab(so.to_unit_float(x))
+        rm = np.asarray(ref_mean, dtype=np.float32).reshape(1, 3, 1, 1)
+        rs = np.asarray(ref_std, dtype=np.float32).reshape(1, 3, 1, 1)
+        mu = (mean + 128.0).astype(np.float32).reshape(1, 3, 1, 1)
+        sd = std.astype(np.float32).reshape(1, 3, 1, 1)
+        lab_n = ((lab - mu) / (sd + np.float32(1e-8))) * rs + rm
+        rgb = np.clip(so.lab_to_rgb(lab_n.astype(np.float32)), 0, 1)
+        return torch.from_numpy(so.restore_dtype(rgb, x.dtype, in_0_255=False))
+
+
+class NumpyHMSteps:
+    def local_counts(self, images):
+        u8, _ = so.images_to_uint8(images.numpy())
+        return torch.from_numpy(np.stack([np.bincount(u8[:, c].reshape(-1), minlength=256) for c in range(3)]).astype(np.int64))
+
+    def apply_with_counts(self, images, counts, n_total, ref_hists):
+        x = images.numpy()
+        u8, scaled = so.images_to_uint8(x)
+        out = np.empty(u8.shape, dtype=np.float32)
+        for c in range(3):
+            lut = so.hm_lut(counts[c].numpy(), np.asarray(ref_hists[c]), n_total)
+            out[:, c] = lut[u8[:, c]]
+        if scaled:
+            return torch.from_numpy(so.restore_dtype(np.clip(out / np.float32(255), 0, 1), x.dtype, in_0_255=False))
+        return torch.from_numpy(so.restore_dtype(np.clip(out, 0, 255), x.dtype, in_0_255=True))

@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU choreography in stainx_amd/distributed.py: the sequence of
+small all-reduces yields, on every rank, the result of the single-process oracle on the whole batch."""
+from __future__ import annotations
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import stain_oracle as so
+from stainx_amd import distributed as sxd
+from stainx_amd import synth
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world_size: int, port: int, out_dir: str):
+    from tests._numpy_steps import NumpyHMSteps, NumpyMacenkoSteps, NumpyReinhardSteps
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        tiles = synth.he_batch(5, 64, 64, seed0=200, scale_step=0.04)          # 5 tiles over 2 ranks: 3 + 2
+        lo, hi = sxd.shard_bounds(tiles.shape[0], rank, world_size)
+        local = tiles[lo:hi]
+        he, max_c = sxd.macenko_fit_pooled(local, steps=NumpyMacenkoSteps())
+        noise = synth.noise_u8((5, 3, 32, 32), 11)
+        ref_mean, ref_std = so.reinhard_fit(synth.noise_u8((1, 3, 32, 32), 12).numpy())
+        rein = sxd.reinhard_transform_pooled(noise[lo:hi], ref_mean, ref_std, steps=NumpyReinhardSteps())
+        hists = so.hm_fit(synth.noise_u8((1, 3, 32, 32), 12).numpy())
+        hm = sxd.hm_transform_pooled(noise[lo:hi], hists, steps=NumpyHMSteps())
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), he=he.numpy(), max_c=max_c.numpy(), rein=rein.numpy(), hm=hm.numpy(), lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    assert [sxd.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert sxd.shard_bounds(2, 3, 4) == (2, 2)
+    assert sxd.world() == (0, 1)
+    t = torch.ones(3)
+    assert sxd.all_reduce_sum(t) is t and float(t.sum()) == 3.0          # world size 1: no-op
+
+
+def test_two_rank_gloo_matches_single_process_oracle(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    tiles = synth.he_batch(5, 64, 64, seed0=200, scale_step=0.04)
+    he, max_c = so.macenko_fit(tiles.numpy(), signs="positive_sum")
+    for r in (r0, r1):
+        np.testing.assert_allclose(r["he"], he, atol=2e-5)
+        np.testing.assert_allclose(r["max_c"], max_c, rtol=2e-5)
+    np.testing.assert_array_equal(r0["he"], r1["he"])                    # rank-invariant bits
+    np.testing.assert_array_equal(r0["max_c"], r1["max_c"])
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 3, 3, 5)
+    noise = synth.noise_u8((5, 3, 32, 32), 11).numpy()
+    ref = synth.noise_u8((1, 3, 32, 32), 12).numpy()
+    want_rein = so.reinhard_transform(noise, *so.reinhard_fit(ref))
+    got_rein = np.concatenate([r0["rein"], r1["rein"]])
+    assert np.abs(got_rein.astype(int) - want_rein.astype(int)).max() <= 1
+    want_hm = so.hm_transform(noise, so.hm_fit(ref))
+    np.testing.assert_array_equal(np.concatenate([r0["hm"], r1["hm"]]), want_hm)
+    # and pooling matters: per-shard statistics give a different answer
+    assert not np.array_equal(so.hm_transform(noise[:3], so.hm_fit(ref)), r0["hm"])

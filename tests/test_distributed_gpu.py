@@ -1,0 +1,87 @@
+"""GPU tests of the staged (multi-rank) entry points: world size 1 directly, and two processes sharing the one
+GPU of the test box over gloo (RCCL needs one device per rank; the driver's 8-GPU run uses nccl)."""
+from __future__ import annotations
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import stain_oracle as so
+from stainx_amd import distributed as sxd
+from stainx_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_world_size_one_matches_fused_paths(golden):
+    from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP, MacenkoHIP, ReinhardHIP
+
+    dev = torch.device("cuda:0")
+    g = golden("g3_macenko_fit.npz")
+    for tag in ("pooled4x224", "pooled8x128", "single64"):
+        tiles = torch.from_numpy(g[f"{tag}_u8"]).to(dev)
+        he, max_c = sxd.macenko_fit_pooled(tiles)
+        np.testing.assert_allclose(he.cpu().numpy(), g[f"{tag}_he"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(max_c.cpu().numpy(), g[f"{tag}_max_c"], rtol=1e-4, atol=0)
+        he2, mc2 = MacenkoHIP(dev).compute_reference_stain_matrix(tiles)
+        assert torch.equal(he, he2) and torch.equal(max_c, mc2)          # radix-select fit == bracketed fit, bit for bit
+    noise = synth.noise_u8((3, 3, 67, 45), 43).to(dev)
+    ref = synth.noise_u8((1, 3, 67, 45), 42).to(dev)
+    rb = ReinhardHIP(dev)
+    mean, std = rb.compute_reference_mean_std(ref)
+    assert torch.equal(sxd.reinhard_transform_pooled(noise, mean, std), rb.transform(noise, mean, std))
+    hb = HistogramMatchingHIP(dev)
+    hists = hb.compute_reference_histograms(ref)
+    assert torch.equal(sxd.hm_transform_pooled(noise, hists), hb.transform(noise, hists))
+
+
+def _worker(rank: int, world_size: int, port: int, out_dir: str):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        dev = torch.device("cuda:0")
+        tiles = synth.he_batch(8, 128, 128)
+        lo, hi = sxd.shard_bounds(8, rank, world_size)
+        he, max_c = sxd.macenko_fit_pooled(tiles[lo:hi].to(dev))
+        noise = synth.noise_u8((5, 3, 64, 64), 11)
+        ref = synth.noise_u8((1, 3, 64, 64), 12)
+        l2, h2 = sxd.shard_bounds(5, rank, world_size)
+        from stainx_amd import HistogramMatching, Reinhard
+
+        rn = Reinhard(device=dev).fit(ref)
+        rein = sxd.reinhard_transform_pooled(noise[l2:h2].to(dev), rn._reference_mean, rn._reference_std)
+        hn = HistogramMatching(device=dev).fit(ref)
+        hm = sxd.hm_transform_pooled(noise[l2:h2].to(dev), hn._ref_histograms_256)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), he=he.cpu().numpy(), max_c=max_c.cpu().numpy(), rein=rein.cpu().numpy(), hm=hm.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu(tmp_path, golden):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    g = golden("g3_macenko_fit.npz")
+    assert np.array_equal(synth.he_batch(8, 128, 128).numpy(), g["pooled8x128_u8"])
+    for r in (r0, r1):
+        np.testing.assert_allclose(r["he"], g["pooled8x128_he"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(r["max_c"], g["pooled8x128_max_c"], rtol=1e-4, atol=0)
+    np.testing.assert_array_equal(r0["he"], r1["he"])
+    np.testing.assert_array_equal(r0["max_c"], r1["max_c"])
+    noise = synth.noise_u8((5, 3, 64, 64), 11).numpy()
+    ref = synth.noise_u8((1, 3, 64, 64), 12).numpy()
+    want_hm = so.hm_transform(noise, so.hm_fit(ref))
+    np.testing.assert_array_equal(np.concatenate([r0["hm"], r1["hm"]]), want_hm)
+    want_rein = so.reinhard_transform(noise, *so.reinhard_fit(ref))
+    assert np.abs(np.concatenate([r0["rein"], r1["rein"]]).astype(int) - want_rein.astype(int)).max() <= 1
