@@ -51,6 +51,8 @@ struct alignas(256) GroupState {
     unsigned long long n_sel;     // pixels in the selection set (kept by the OD filter, or all)
     unsigned long long rank[kSlots];   // wanted 0-based rank inside the selection set
     uint32_t lo_key[kSlots], hi_key[kSlots];
+    double bin_origin[kSlots], bin_scale[kSlots];   // bracket-relative bin of a candidate: (value - origin) * scale
+    uint32_t hist_bad;            // bit s: a workgroup's LDS queue spilled, block histograms of slot s are incomplete
     uint32_t below[kSlots];       // keys < lo_key        (atomic, integer => order independent)
     uint32_t ncand[kSlots];       // keys in [lo_key,hi_key] (atomic)
     uint32_t ncand_seen[kSlots];  // copy kept for sx_macenko_tile_params
@@ -70,6 +72,8 @@ struct Workspace {
     GroupState* state;
     double* partial;              // [n_tiles*blocks_per_tile][kMoments]
     uint32_t* cand;               // [groups][kSlots][kCap]
+    uint32_t* block_hist;         // [n_tiles*blocks_per_tile][2][256] bracket-relative histograms of a pass's candidates
+    float* sample_od;             // [groups][3][kSample] OD of the strided sample (written once, read by both per-tile kernels)
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -84,6 +88,8 @@ static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
     size_t total = align_up(sizeof(GroupState) * (size_t)n_tiles, 256);
     total += align_up(sizeof(double) * kMoments * b * (size_t)n_tiles, 256);
     total += align_up(sizeof(uint32_t) * kSlots * kCap * (size_t)n_tiles, 256);
+    total += align_up(sizeof(uint32_t) * 2 * 256 * b * (size_t)n_tiles, 256);
+    total += align_up(sizeof(float) * 3 * kSample * (size_t)n_tiles, 256);
     return total;
 }
 
@@ -96,6 +102,10 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     w.partial = reinterpret_cast<double*>(p);
     p += align_up(sizeof(double) * kMoments * b * (size_t)n_tiles, 256);
     w.cand = reinterpret_cast<uint32_t*>(p);
+    p += align_up(sizeof(uint32_t) * kSlots * kCap * (size_t)n_tiles, 256);
+    w.block_hist = reinterpret_cast<uint32_t*>(p);
+    p += align_up(sizeof(uint32_t) * 2 * 256 * b * (size_t)n_tiles, 256);
+    w.sample_od = reinterpret_cast<float*>(p);
     return w;
 }
 
@@ -341,6 +351,33 @@ __device__ __forceinline__ void scan_pick(const uint32_t* hist, unsigned long lo
     rank_in_bin = r;
 }
 
+// Bracket-relative bin (0..255) of a key in [lo,hi], linear in the float VALUE the key stands for (key-linear
+// bins would crowd: float keys spend one binade per exponent) and monotone in the key.  scale = 256/(v_hi-v_lo);
+// an open or degenerate bracket gets scale 0 (everything in bin 0 -> the radix paths take over).
+__device__ __forceinline__ uint32_t bin_of(uint32_t key, double lo_value, double scale) {
+    const double d = ((double)key_float(key) - lo_value) * scale;
+    return (uint32_t)fmin(fmax(d, 0.0), 255.0);     // values beyond the range (open brackets) go to the end bins
+}
+__device__ __forceinline__ double bin_origin_for(uint32_t lo) { return (double)key_float(lo); }
+__device__ __forceinline__ double bin_scale_for(uint32_t lo, uint32_t hi) {
+    const double span = (double)key_float(hi) - (double)key_float(lo);
+    return (span > 0.0 && span < 1e300) ? 256.0 / span : 0.0;
+}
+
+// Exact r-th smallest (0-based, ties by index) of a short LDS list by rank counting; the owner writes *out.
+__device__ __forceinline__ void rank_pick(const uint32_t* list, uint32_t n, unsigned long long r, uint32_t* out) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t k = list[i];
+        uint32_t c = 0;
+#pragma unroll 16
+        for (uint32_t t = 0; t < n; ++t) {
+            const uint32_t x = list[t];
+            c += (x < k || (x == k && t < i)) ? 1u : 0u;
+        }
+        if (c == r) *out = k;
+    }
+}
+
 struct SelectJob {
     uint32_t count;              // 0: nothing to select
     unsigned long long rank;     // 0-based, among the keys that lie in [lo,hi]
@@ -481,23 +518,38 @@ __device__ __forceinline__ int64_t sample_position(int j, int m, int64_t count) 
 
 constexpr int kSamplePerThread = kSample / kGroupThreads;   // 4 sample keys per thread, kept in registers
 
+constexpr int kShortList = 1024;   // keys of one histogram bin gathered for rank counting
+
 struct SampleShared {
-    SelectShared<4> sel;
+    union {
+        SelectShared<4> sel;                 // radix fallback
+        struct {
+            uint32_t hist[2][256];           // one histogram per key set
+            uint32_t list[4][kShortList];    // keys of the four picked bins
+        } two;
+    };
     uint32_t lo[2], hi[2];
+    uint32_t bin[4], count[4], result[4];
+    unsigned long long rank_in_bin[4];
     int valid;
 };
 
 // Brackets for two wanted ranks (k0[0], k0[1]) in key sets A and B from the rank statistics of a
-// kSample-key sample spread over the workgroup's registers (invalid entries are 0xFFFFFFFF): min/max of
-// each set, then four order statistics of the sample in one multi_select.
+// kSample-key sample spread over the workgroup's registers (invalid entries are 0xFFFFFFFF).
+// Four sample order statistics (two ranks per key set) in two levels: one 256-bin histogram per key set over
+// [min,max] (a single round of LDS atomics), one wave per rank picks its bin, the keys of that bin
+// are gathered and the exact element is found by rank counting.  A crowded bin (> kShortList keys)
+// falls back to the radix rounds of multi_select.
 template <int NSETS>
 __device__ void sample_brackets(const uint32_t (&keys)[NSETS][kSamplePerThread], unsigned long long n_total, const unsigned long long (&k0)[2], uint32_t (&lo)[2],
-                                uint32_t (&hi)[2], SampleShared* sh) {
-    if (threadIdx.x == 0) {
-        sh->lo[0] = sh->lo[1] = 0xFFFFFFFFu;
-        sh->hi[0] = sh->hi[1] = 0u;
-        sh->valid = 0;
+                                uint32_t (&hi)[2], double (&bin_origin)[2], double (&bin_scale)[2], SampleShared* sh) {
+    if (threadIdx.x < 2) {
+        sh->lo[threadIdx.x] = 0xFFFFFFFFu;
+        sh->hi[threadIdx.x] = 0u;
     }
+    if (threadIdx.x < 4) sh->count[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sh->valid = 0;
+    for (int t = threadIdx.x; t < 2 * 256; t += blockDim.x) (&sh->two.hist[0][0])[t] = 0;
     __syncthreads();
     int valid = 0;
 #pragma unroll
@@ -527,25 +579,97 @@ __device__ void sample_brackets(const uint32_t (&keys)[NSETS][kSamplePerThread],
     __syncthreads();
     const int m_valid = sh->valid;
     long long lo_r[2], hi_r[2];
-    SelectJob job[4];
-    const int set_of[4] = {0, 0, NSETS - 1, NSETS - 1};
-    int n_mine[NSETS];
+    bool want[4];
+    unsigned long long rank[4];
+    uint32_t set_lo[NSETS], set_hi[NSETS];
+    double origin[NSETS], scale[NSETS];
 #pragma unroll
-    for (int set = 0; set < NSETS; ++set) n_mine[set] = kSamplePerThread;
+    for (int set = 0; set < NSETS; ++set) {
+        set_lo[set] = sh->lo[set];
+        set_hi[set] = sh->hi[set];
+        origin[set] = bin_origin_for(set_lo[set]);
+        scale[set] = bin_scale_for(set_lo[set], set_hi[set]);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         bracket_ranks(m_valid, n_total, k0[s], lo_r[s], hi_r[s]);
-        const int set = s == 0 ? 0 : NSETS - 1;
-        const bool has = m_valid > 0;
-        job[2 * s] = SelectJob{has && lo_r[s] >= 0 ? (uint32_t)kSample : 0u, (unsigned long long)(lo_r[s] < 0 ? 0 : lo_r[s]), sh->lo[set], sh->hi[set]};
-        job[2 * s + 1] = SelectJob{has && hi_r[s] < m_valid ? (uint32_t)kSample : 0u, (unsigned long long)(hi_r[s] < 0 ? 0 : hi_r[s]), sh->lo[set], sh->hi[set]};
+        want[2 * s] = m_valid > 0 && lo_r[s] >= 0;
+        want[2 * s + 1] = m_valid > 0 && hi_r[s] < m_valid;
+        rank[2 * s] = (unsigned long long)(lo_r[s] < 0 ? 0 : lo_r[s]);
+        rank[2 * s + 1] = (unsigned long long)(hi_r[s] < 0 ? 0 : hi_r[s]);
     }
+    // level 1: histograms
+#pragma unroll
+    for (int set = 0; set < NSETS; ++set)
+#pragma unroll
+        for (int i = 0; i < kSamplePerThread; ++i) {
+            const uint32_t k = keys[set][i];
+            if (k != 0xFFFFFFFFu) atomicAdd(&sh->two.hist[set][bin_of(k, origin[set], scale[set])], 1u);
+        }
+    __syncthreads();
+    const int wave = threadIdx.x / kWave;
+    if (wave < 4 && want[wave < 4 ? wave : 0]) {
+        const int set = (wave >> 1) ? NSETS - 1 : 0;
+        uint32_t b;
+        unsigned long long rb;
+        scan_pick(sh->two.hist[set], rank[wave], b, rb);
+        if (lane_id() == 0) {
+            sh->bin[wave] = b;
+            sh->rank_in_bin[wave] = rb;
+        }
+    }
+    __syncthreads();
+    // level 2: gather the picked bins, rank-count inside them
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!want[j]) continue;
+        const int set = (j >> 1) ? NSETS - 1 : 0;
+        const uint32_t b = sh->bin[j];
+#pragma unroll
+        for (int i = 0; i < kSamplePerThread; ++i) {
+            const uint32_t k = keys[set][i];
+            if (k != 0xFFFFFFFFu && bin_of(k, origin[set], scale[set]) == b) {
+                const uint32_t idx = atomicAdd(&sh->count[j], 1u);
+                if (idx < (uint32_t)kShortList) sh->two.list[j][idx] = k;
+            }
+        }
+    }
+    __syncthreads();
+    bool crowded = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!want[j]) continue;
+        if (sh->count[j] > (uint32_t)kShortList) crowded = true;
+        else rank_pick(sh->two.list[j], sh->count[j], sh->rank_in_bin[j], &sh->result[j]);
+    }
+    __syncthreads();
     uint32_t res[4];
-    multi_select<4, NSETS, kSamplePerThread>(keys, n_mine, set_of, job, res, &sh->sel);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) res[j] = sh->result[j];
+    if (crowded) {   // uniform: the counts live in LDS
+        __syncthreads();
+        SelectJob job[4];
+        const int set_of[4] = {0, 0, NSETS - 1, NSETS - 1};
+        int n_mine[NSETS];
+#pragma unroll
+        for (int set = 0; set < NSETS; ++set) n_mine[set] = kSamplePerThread;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int set = (j >> 1) ? NSETS - 1 : 0;
+            job[j] = SelectJob{want[j] ? (uint32_t)kSample : 0u, rank[j], set_lo[set], set_hi[set]};
+        }
+        multi_select<4, NSETS, kSamplePerThread>(keys, n_mine, set_of, job, res, &sh->sel);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        lo[s] = job[2 * s].count ? res[2 * s] : 0u;
-        hi[s] = job[2 * s + 1].count ? res[2 * s + 1] : 0xFFFFFFFFu;
+        const int set = s ? NSETS - 1 : 0;
+        lo[s] = want[2 * s] ? res[2 * s] : 0u;
+        hi[s] = want[2 * s + 1] ? res[2 * s + 1] : 0xFFFFFFFFu;
+        // candidate bins span the bracket; an open side is bounded by the sample's extreme (the few keys beyond it
+        // fall into the end bin)
+        const uint32_t range_lo = want[2 * s] ? res[2 * s] : set_lo[set], range_hi = want[2 * s + 1] ? res[2 * s + 1] : set_hi[set];
+        bin_origin[s] = bin_origin_for(range_lo);
+        bin_scale[s] = m_valid > 0 ? bin_scale_for(range_lo, range_hi) : 0.0;
     }
 }
 
@@ -595,6 +719,20 @@ __global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restric
     __shared__ int use_all_s;
     __shared__ unsigned long long n_sel_s;
 
+    // strided sample of the group's pixels: issue the scattered loads first, they land while the moments are
+    // summed and the covariance is diagonalised
+    const int m = (int)min((int64_t)kSample, gp.count);
+    float sample[kSamplePerThread][3];
+#pragma unroll
+    for (int i = 0; i < kSamplePerThread; ++i) {
+        const int j = threadIdx.x + i * kGroupThreads;
+        sample[i][0] = sample[i][1] = sample[i][2] = 0.0f;
+        if (j < m) {
+            int64_t tile, p;
+            gp.locate(sample_position(j, m, gp.count), tile, p);
+            load_od_scalar<T>(images, g.pixels, tile, p, sample[i]);
+        }
+    }
     SX_STAMP(st, 0);
     {
         // fixed-order (deterministic) sum of the workgroup partials: lanes fetch them in parallel, one thread
@@ -633,37 +771,33 @@ __global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restric
         st.use_all = use_all_s;
         st.n_sel = n_sel_s;
         st.fell_back = 0;
+        st.hist_bad = 0;
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) st.below[s] = st.ncand[s] = 0;
     }
     __syncthreads();
 
     SX_STAMP(st, 2);
-    // strided sample of the group's pixels -> angle keys of the selected ones
-    const int m = (int)min((int64_t)kSample, gp.count);
+    // angle keys of the selected sample pixels; the sample's OD is kept for the concentration brackets
     const bool use_all = use_all_s != 0;
     float v[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) v[i] = v_s[i];
     uint32_t keys[1][kSamplePerThread];
+    float* sample_out = ws.sample_od + (size_t)group * 3 * kSample;
 #pragma unroll
     for (int i = 0; i < kSamplePerThread; ++i) {
         const int j = threadIdx.x + i * kGroupThreads;
-        uint32_t key = 0xFFFFFFFFu;
-        if (j < m) {
-            int64_t tile, p;
-            gp.locate(sample_position(j, m, gp.count), tile, p);
-            float od[3];
-            load_od_scalar<T>(images, g.pixels, tile, p, od);
-            if (od_selected(od, use_all)) key = angle_key(od, v);
-        }
-        keys[0][i] = key;
+        keys[0][i] = (j < m && od_selected(sample[i], use_all)) ? angle_key(sample[i], v) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sample_out[c * kSample + j] = sample[i][c];
     }
     const unsigned long long n_sel = n_sel_s;
     const unsigned long long k0[2] = {nearest_rank_index(1.0, n_sel), nearest_rank_index(99.0, n_sel)};   // alpha = 1 (torch_backend.py:421-422)
     uint32_t lo[2], hi[2];
+    double b_origin[2], b_scale[2];
     SX_STAMP(st, 3);
-    sample_brackets<1>(keys, n_sel, k0, lo, hi, &sample_sh);
+    sample_brackets<1>(keys, n_sel, k0, lo, hi, b_origin, b_scale, &sample_sh);
     SX_STAMP(st, 4);
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -671,6 +805,8 @@ __global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restric
             st.rank[s] = k0[s];
             st.lo_key[s] = lo[s];
             st.hi_key[s] = hi[s];
+            st.bin_origin[s] = b_origin[s];
+            st.bin_scale[s] = b_scale[s];
         }
     }
 }
@@ -681,23 +817,14 @@ __global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restric
 //   kConc == true : slots 2,3 use the two concentrations of every pixel
 // Candidates are first queued in LDS; one global atomic per workgroup and slot reserves their place.
 // ------------------------------------------------------------------------------------------------
-constexpr int kLocalCap = 2048;
+constexpr int kLocalCap = 4096;        // LDS queue per slot = pixels a workgroup handles between two flushes
 
 struct LocalQueue {
     uint32_t count[2];
     uint32_t base[2];
     uint32_t keys[2][kLocalCap];
+    uint32_t hist[2][256];        // bracket-relative histogram of everything this workgroup queued
 };
-
-__device__ __forceinline__ void enqueue(LocalQueue& q, int which, uint32_t key, uint32_t* __restrict__ global_count, uint32_t* __restrict__ global_buf) {
-    const uint32_t idx = atomicAdd(&q.count[which], 1u);
-    if (idx < (uint32_t)kLocalCap) {
-        q.keys[which][idx] = key;
-    } else {   // rare: LDS queue full, go straight to the tile's buffer
-        const uint32_t gidx = atomicAdd(global_count, 1u);
-        if (gidx < (uint32_t)kCap) global_buf[gidx] = key;
-    }
-}
 
 template <typename T, int V, bool kConc>
 __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
@@ -713,6 +840,7 @@ __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __rest
     __shared__ LocalQueue queue;
     __shared__ uint32_t red[2][kStreamThreads / kWave];
     if (threadIdx.x < 2) queue.count[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 512; i += kStreamThreads) (&queue.hist[0][0])[i] = 0;
     __syncthreads();
 
     float coef[6];
@@ -720,34 +848,61 @@ __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __rest
     for (int i = 0; i < 6; ++i) coef[i] = kConc ? st.pinv[i] : st.vecs[i];
     const bool use_all = kConc ? true : (st.use_all != 0);
     const uint32_t lo_a = st.lo_key[s0], hi_a = st.hi_key[s0], lo_b = st.lo_key[s0 + 1], hi_b = st.hi_key[s0 + 1];
+    const double scale_a = st.bin_scale[s0], scale_b = st.bin_scale[s0 + 1], origin_a = st.bin_origin[s0], origin_b = st.bin_origin[s0 + 1];
     uint32_t* cand_a = ws.cand + ((size_t)group * kSlots + s0) * kCap;
     uint32_t* cand_b = cand_a + kCap;
     uint32_t below_a = 0, below_b = 0;
 
-    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
-        float u[3][V];
+    // The chunk is walked in phases of kLocalCap pixels; after each phase the LDS queues (which therefore
+    // cannot overflow) are moved to the tile's candidate buffers with ONE global atomic per slot.
+    constexpr int kPhasePixels = kLocalCap;
+    for (int64_t phase_begin = p_begin; phase_begin < p_end; phase_begin += kPhasePixels) {
+        const int64_t phase_end = min(phase_begin + kPhasePixels, p_end);
+        for (int64_t p = phase_begin + (int64_t)threadIdx.x * V; p < phase_end; p += (int64_t)kStreamThreads * V) {
+            float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+            for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float od[3];
+            for (int i = 0; i < V; ++i) {
+                float od[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
-            const bool valid = od_selected(od, use_all);
-            uint32_t key_a, key_b;
-            if constexpr (kConc) {
-                float c0, c1;
-                concentration(od, coef, c0, c1);
-                key_a = float_key(c0);
-                key_b = float_key(c1);
-            } else {
-                key_a = key_b = angle_key(od, coef);
+                for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
+                const bool valid = od_selected(od, use_all);
+                uint32_t key_a, key_b;
+                if constexpr (kConc) {
+                    float c0, c1;
+                    concentration(od, coef, c0, c1);
+                    key_a = float_key(c0);
+                    key_b = float_key(c1);
+                } else {
+                    key_a = key_b = angle_key(od, coef);
+                }
+                below_a += (valid && key_a < lo_a) ? 1u : 0u;
+                below_b += (valid && key_b < lo_b) ? 1u : 0u;
+                if (valid && key_a >= lo_a && key_a <= hi_a) queue.keys[0][atomicAdd(&queue.count[0], 1u)] = key_a;
+                if (valid && key_b >= lo_b && key_b <= hi_b) queue.keys[1][atomicAdd(&queue.count[1], 1u)] = key_b;
             }
-            below_a += (valid && key_a < lo_a) ? 1u : 0u;
-            below_b += (valid && key_b < lo_b) ? 1u : 0u;
-            if (valid && key_a >= lo_a && key_a <= hi_a) enqueue(queue, 0, key_a, &st.ncand[s0], cand_a);
-            if (valid && key_b >= lo_b && key_b <= hi_b) enqueue(queue, 1, key_b, &st.ncand[s0 + 1], cand_b);
         }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const uint32_t n_local = queue.count[threadIdx.x];
+            queue.base[threadIdx.x] = n_local ? atomicAdd(&st.ncand[s0 + threadIdx.x], n_local) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            uint32_t* dst = which == 0 ? cand_a : cand_b;
+            const uint32_t n_local = queue.count[which], base = queue.base[which];
+            const double origin = which == 0 ? origin_a : origin_b, scale = which == 0 ? scale_a : scale_b;
+            for (uint32_t i = threadIdx.x; i < n_local; i += kStreamThreads) {
+                const uint32_t key = queue.keys[which][i];
+                if (base + i < (uint32_t)kCap) dst[base + i] = key;
+                atomicAdd(&queue.hist[which][bin_of(key, origin, scale)], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) queue.count[threadIdx.x] = 0;
+        __syncthreads();
     }
 
     const uint32_t wa = wave_sum_u32(below_a), wb = wave_sum_u32(below_b);
@@ -757,22 +912,15 @@ __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __rest
     }
     __syncthreads();
     if (threadIdx.x < 2) {
-        uint32_t s = 0;
+        uint32_t sum = 0;
 #pragma unroll
-        for (int w = 0; w < kStreamThreads / kWave; ++w) s += red[threadIdx.x][w];
-        if (s) atomicAdd(&st.below[s0 + threadIdx.x], s);
-        const uint32_t n_local = min(queue.count[threadIdx.x], (uint32_t)kLocalCap);
-        queue.base[threadIdx.x] = n_local ? atomicAdd(&st.ncand[s0 + threadIdx.x], n_local) : 0u;
-        queue.count[threadIdx.x] = n_local;
+        for (int w = 0; w < kStreamThreads / kWave; ++w) sum += red[threadIdx.x][w];
+        if (sum) atomicAdd(&st.below[s0 + threadIdx.x], sum);
     }
-    __syncthreads();
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        uint32_t* dst = which == 0 ? cand_a : cand_b;
-        const uint32_t n_local = queue.count[which], base = queue.base[which];
-        for (uint32_t i = threadIdx.x; i < n_local; i += kStreamThreads)
-            if (base + i < (uint32_t)kCap) dst[base + i] = queue.keys[which][i];
-    }
+    // the workgroup's histograms are stored -- not added -- so the per-tile kernel can sum them in a fixed
+    // order without any global atomic
+    uint32_t* hist_out = ws.block_hist + (size_t)blockIdx.x * 512;
+    for (int i = threadIdx.x; i < 512; i += kStreamThreads) hist_out[i] = (&queue.hist[0][0])[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -808,7 +956,7 @@ __device__ uint32_t select_whole_group(const T* __restrict__ images, const Geome
 constexpr int kCandPerThread = kCap / kGroupThreads;   // 16 candidate keys per thread and slot, in registers
 
 template <typename T>
-__device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, uint32_t (&key_out)[2], SelectShared<4>* sh) {
+__device__ void resolve_pair_radix(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, uint32_t (&key_out)[2], SelectShared<4>* sh) {
     GroupState& st = ws.state[group];
     SelectJob job[2];
     bool ok[2];
@@ -841,6 +989,104 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
     }
 }
 
+struct ResolveShared {
+    union {
+        SelectShared<4> sel;                  // radix fallback / whole-group select
+        struct {
+            uint32_t hist[2][256];
+            uint32_t list[2][kShortList];
+        } two;
+    };
+    uint32_t bin[2], count[2], result[2];
+    unsigned long long rank_in_bin[2];
+};
+
+// Exact order statistics of two slots from the candidates gathered by the streaming pass, in two levels:
+// sum the workgroups' bracket-relative histograms (fixed order), one wave per slot picks the bin holding the
+// wanted rank, the candidates of that bin (~n/256 keys) are gathered and rank-counted.  Anything unusual --
+// bracket missed or overflowed, a spilled queue, a crowded bin -- goes to the radix / whole-group paths.
+template <typename T>
+__device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, uint32_t (&key_out)[2], ResolveShared* sh) {
+    GroupState& st = ws.state[group];
+    bool ok[2];
+    uint32_t ncand[2];
+    double origin[2], scale[2];
+    unsigned long long want_in[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int slot = first_slot + j;
+        ncand[j] = st.ncand[slot];
+        const unsigned long long below = st.below[slot], want = st.rank[slot];
+        ok[j] = ncand[j] <= (uint32_t)kCap && want >= below && want - below < ncand[j] && ((st.hist_bad >> slot) & 1u) == 0;
+        want_in[j] = ok[j] ? want - below : 0ull;
+        origin[j] = st.bin_origin[slot];
+        scale[j] = st.bin_scale[slot];
+    }
+    bool simple = ok[0] && ok[1];
+    if (simple) {
+        const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
+        const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
+        if (threadIdx.x < 2) sh->count[threadIdx.x] = 0;
+        if (threadIdx.x < 512) {                       // thread t owns bin t%256 of slot t/256
+            const uint32_t* src = ws.block_hist + first * 512 + threadIdx.x;
+            uint32_t sum = 0;
+#pragma unroll 8
+            for (int64_t b = 0; b < nblk; ++b) sum += src[b * 512];
+            (&sh->two.hist[0][0])[threadIdx.x] = sum;
+        }
+        __syncthreads();
+        if (first_slot == 2) SX_STAMP(st, 5);
+        const int wave = threadIdx.x / kWave;
+        if (wave < 2) {
+            uint32_t b;
+            unsigned long long rb;
+            scan_pick(sh->two.hist[wave], want_in[wave], b, rb);
+            if (lane_id() == 0) {
+                sh->bin[wave] = b;
+                sh->rank_in_bin[wave] = rb;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t* cand = ws.cand + ((size_t)group * kSlots + first_slot + j) * kCap;
+            const uint32_t b = sh->bin[j];
+            for (uint32_t base = threadIdx.x; base < ncand[j]; base += kGroupThreads * 8) {
+                uint32_t k[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {          // eight independent loads in flight
+                    const uint32_t idx = base + u * kGroupThreads;
+                    k[u] = idx < ncand[j] ? cand[idx] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t idx = base + u * kGroupThreads;
+                    if (idx < ncand[j] && bin_of(k[u], origin[j], scale[j]) == b) {
+                        const uint32_t at = atomicAdd(&sh->count[j], 1u);
+                        if (at < (uint32_t)kShortList) sh->two.list[j][at] = k[u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (first_slot == 2) SX_STAMP(st, 11);
+        if (sh->count[0] > (uint32_t)kShortList || sh->count[1] > (uint32_t)kShortList) {
+            simple = false;                            // crowded bin (heavy ties): radix rounds instead
+        } else {
+            rank_pick(sh->two.list[0], sh->count[0], sh->rank_in_bin[0], &sh->result[0]);
+            rank_pick(sh->two.list[1], sh->count[1], sh->rank_in_bin[1], &sh->result[1]);
+            __syncthreads();
+            if (first_slot == 2) SX_STAMP(st, 14);
+            key_out[0] = sh->result[0];
+            key_out[1] = sh->result[1];
+        }
+    }
+    if (!simple) {
+        __syncthreads();
+        resolve_pair_radix<T>(images, g, ws, group, first_slot, key_out, &sh->sel);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-tile kernel B: angle percentiles -> HE_source -> pseudo-inverse; concentration brackets
 // ------------------------------------------------------------------------------------------------
@@ -849,12 +1095,16 @@ __global__ __launch_bounds__(kGroupThreads) void stain_kernel(const T* __restric
     const int group = blockIdx.x;
     GroupState& st = ws.state[group];
     const GroupPixels gp = group_pixels(g, group);
-    __shared__ SampleShared sample_sh;
+    __shared__ union {
+        SampleShared sample;
+        ResolveShared resolve;
+    } lds;
+    SampleShared& sample_sh = lds.sample;
     __shared__ float pinv_s[6];
 
     uint32_t phi_key[2];
     SX_STAMP(st, 6);
-    resolve_pair<T>(images, g, ws, group, 0, phi_key, &sample_sh.sel);
+    resolve_pair<T>(images, g, ws, group, 0, phi_key, &lds.resolve);
     __syncthreads();
     SX_STAMP(st, 7);
 
@@ -881,15 +1131,14 @@ __global__ __launch_bounds__(kGroupThreads) void stain_kernel(const T* __restric
 #pragma unroll
     for (int i = 0; i < 6; ++i) pinv[i] = pinv_s[i];
     uint32_t keys[2][kSamplePerThread];
+    const float* sample_in = ws.sample_od + (size_t)group * 3 * kSample;
 #pragma unroll
     for (int i = 0; i < kSamplePerThread; ++i) {
         const int j = threadIdx.x + i * kGroupThreads;
         uint32_t ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
         if (j < m) {
-            int64_t tile, p;
-            gp.locate(sample_position(j, m, gp.count), tile, p);
-            float od[3], c0, c1;
-            load_od_scalar<T>(images, g.pixels, tile, p, od);
+            const float od[3] = {sample_in[j], sample_in[kSample + j], sample_in[2 * kSample + j]};
+            float c0, c1;
             concentration(od, pinv, c0, c1);
             ka = float_key(c0);
             kb = float_key(c1);
@@ -901,8 +1150,9 @@ __global__ __launch_bounds__(kGroupThreads) void stain_kernel(const T* __restric
     const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
     const unsigned long long k0[2] = {k99, k99};
     uint32_t lo[2], hi[2];
+    double b_origin[2], b_scale[2];
     SX_STAMP(st, 9);
-    sample_brackets<2>(keys, n_all, k0, lo, hi, &sample_sh);
+    sample_brackets<2>(keys, n_all, k0, lo, hi, b_origin, b_scale, &sample_sh);
     SX_STAMP(st, 10);
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -910,6 +1160,8 @@ __global__ __launch_bounds__(kGroupThreads) void stain_kernel(const T* __restric
             st.rank[2 + s] = k99;
             st.lo_key[2 + s] = lo[s];
             st.hi_key[2 + s] = hi[s];
+            st.bin_origin[2 + s] = b_origin[s];
+            st.bin_scale[2 + s] = b_scale[s];
         }
     }
 }
@@ -921,7 +1173,7 @@ template <typename T>
 __global__ __launch_bounds__(kGroupThreads) void scale_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc, float* __restrict__ he_out, float* __restrict__ max_c_out) {
     const int group = blockIdx.x;
     GroupState& st = ws.state[group];
-    __shared__ SelectShared<4> sel;
+    __shared__ ResolveShared sel;
     uint32_t c_key[2];
     SX_STAMP(st, 12);
     resolve_pair<T>(images, g, ws, group, 2, c_key, &sel);
