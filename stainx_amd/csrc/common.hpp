@@ -73,6 +73,41 @@ __device__ __forceinline__ void store_pack(T* __restrict__ p, const T (&vals)[V]
     }
 }
 
+// Streaming (non-temporal) forms for data touched once per launch: the output of a transform is not read again
+// by this library, and a non-temporal store does not leave a dirty line behind for the next reader to wait on.
+template <typename T, int V>
+__device__ __forceinline__ void store_pack_stream(T* __restrict__ p, const T (&vals)[V]) {
+    if constexpr (V == 1 && (sizeof(T) == 4 || sizeof(T) == 8)) {
+        if constexpr (sizeof(T) == 4) {
+            unsigned v;
+            __builtin_memcpy(&v, vals, 4);
+            __builtin_nontemporal_store(v, reinterpret_cast<unsigned*>(p));
+        } else {
+            unsigned long long v;
+            __builtin_memcpy(&v, vals, 8);
+            __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(p));
+        }
+    } else if constexpr (V == 1) {
+        p[0] = vals[0];
+    } else if constexpr (sizeof(T) * V == 16) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 v;
+        __builtin_memcpy(&v, vals, 16);
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
+    } else if constexpr (sizeof(T) * V == 8) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 v;
+        __builtin_memcpy(&v, vals, 8);
+        __builtin_nontemporal_store(v, reinterpret_cast<f2*>(p));
+    } else if constexpr (sizeof(T) * V == 4) {
+        unsigned v;
+        __builtin_memcpy(&v, vals, 4);
+        __builtin_nontemporal_store(v, reinterpret_cast<unsigned*>(p));
+    } else {
+        store_pack<T, V>(p, vals);
+    }
+}
+
 // ---- order-preserving uint32 image of a float (radix / bracket selection keys) ------------------
 __device__ __forceinline__ uint32_t float_key(float f) {
     const uint32_t u = __float_as_uint(f);

@@ -4,34 +4,38 @@
 // rendeirolab/stainx (src/stainx/backends/torch_backend.py:399-560).  How it computes it is this
 // library's own design:
 //
-//   * every pass over the pixels is one streaming kernel (planar NCHW, 16-byte loads per lane,
-//     256-thread workgroups, N*ceil(P/8192) workgroups so the 256 CUs are oversubscribed);
+//   * four streaming stages over the pixels (planar NCHW, 16-byte loads per lane, 256-thread workgroups,
+//     8192 pixels per work item) separated by three small per-tile stages:
+//        S1 moments -> [plane] -> S2 angle pass -> [stain] -> S3 concentration pass -> [scale] -> S4 reconstruct
 //   * the four nearest-rank order statistics per tile (phi@1%, phi@99%, C0@99%, C1@99%;
-//     torch_backend.py:363-365) are EXACT but never sort: a 4096-pixel strided sample of the tile is
-//     sorted in LDS to get a bracket [lo,hi] around each wanted rank; the streaming pass counts the
-//     pixels below the bracket (integer adds) and gathers the few keys inside it; one workgroup per
-//     tile then radix-selects the wanted rank among those candidates.  If a bracket misses or
-//     overflows (heavy ties, adversarial data) that workgroup radix-selects over the whole tile
-//     instead -- slower, same answer;
+//     torch_backend.py:363-365) are EXACT but never sort: a 4096-pixel strided sample of the tile (its
+//     optical density is written out by S1 on the way) gives a bracket [lo,hi] around each wanted rank; the
+//     streaming stage counts the pixels below the bracket (integer adds), gathers the few keys inside it
+//     and histograms them bracket-relative; the per-tile stage sums the work items' histograms in a fixed
+//     order, picks the bin holding the wanted rank and rank-counts the ~n/256 keys of that bin.  If a
+//     bracket misses or overflows, or a bin is crowded (heavy ties, adversarial data), radix selects
+//     over the candidates / over the whole tile give the same answer, slower;
 //   * the 3x3 covariance is accumulated in fp64 (raw moments cancel catastrophically in fp32) and
 //     diagonalised by cyclic Jacobi in fp64; eigenvector signs follow the "positive component sum"
-//     convention (the transform is invariant to them on real H&E tiles).
-//
-// Launch sequence of one transform:  stats -> plane -> angle pass -> stain vectors -> concentration
-// pass -> scale -> reconstruct.  All stream-ordered, no host synchronisation.
+//     convention (the transform is invariant to them on real H&E tiles);
+//   * seven stream-ordered launches per transform, no host synchronisation; the pooled fit (one group over
+//     all tiles) runs the first six with one group.
 #include "common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace sx {
 namespace macenko {
 
-#define SX_STAMP(st, i) do { if (threadIdx.x == 0) (st).stamp[i] = wall_clock64(); } while (0)
-
-constexpr int kSample = 4096;          // sorted sample per tile (LDS bitonic)
+constexpr int kSample = 4096;          // strided sample per tile
 constexpr int kCap = 32768;            // candidate keys per selection slot
-constexpr int kGroupThreads = 1024;    // per-tile scalar kernels
-constexpr int kIters = 8;              // pixel packs per lane per streaming workgroup
+constexpr int kIters = 8;              // pixel packs per lane per work item
+constexpr int kChunk = kStreamThreads * 4 * kIters;   // 8192 pixels per work item
 constexpr int kSlots = 4;              // 0: phi@1  1: phi@99  2: C0@99  3: C1@99
 constexpr int kMoments = 20;           // [cnt,sx,sy,sz,xx,xy,xz,yy,yz,zz] masked, then all pixels
+constexpr int kShortList = 512;        // keys of one histogram bin gathered for rank counting
+constexpr int kPhasePixels = 2048;     // pixels between two flushes of the LDS candidate queues
 
 constexpr float kBeta = 0.15f;         // torch_backend.py:542
 constexpr float kIo = 240.0f;          // torch_backend.py:541
@@ -39,75 +43,91 @@ constexpr float kLn2 = 0.693147180559945309f;
 constexpr float kLnIo = 5.48063892334199f;       // ln 240
 constexpr float kLog2e = 1.44269504088896341f;
 
+// What a streaming stage needs to know about its tile; written once per call by the per-tile stage before
+// it (one record per stage, each on its own 128-byte line).
+struct alignas(128) StageRecord {
+    float coef[6];                // S2: plane vectors (3,2); S3/S4: pseudo-inverse (2,3)
+    float scale[2];               // S4: target_max_conc / max_c
+    uint32_t lo[2], hi[2];        // brackets of the two slots of the stage
+    double bin_origin[2], bin_scale[2];   // bracket-relative bin of a candidate: (value - origin) * scale
+    int32_t use_all;              // S2: fewer than 3 pixels pass the OD filter -> every pixel is selected
+    int32_t pad;
+};
+
 struct alignas(256) GroupState {
+    StageRecord rec[3];           // inputs of S2, S3, S4
     double mom[kMoments];
     double cov[9];
-    float vecs[6];      // (3,2) row-major, columns [middle, largest] eigenvalue
-    float he[6];        // (3,2) row-major HE_source
-    float pinv[6];      // (2,3) row-major pseudo-inverse of HE_source
+    float vecs[6];                // (3,2) row-major, columns [middle, largest] eigenvalue
+    float he[6];                  // (3,2) row-major HE_source
+    float pinv[6];                // (2,3) row-major pseudo-inverse of HE_source
     float phi[2];
     float max_c[2];
-    float scale[2];     // target_max_conc / max_c
     unsigned long long n_sel;     // pixels in the selection set (kept by the OD filter, or all)
     unsigned long long rank[kSlots];   // wanted 0-based rank inside the selection set
-    uint32_t lo_key[kSlots], hi_key[kSlots];
-    double bin_origin[kSlots], bin_scale[kSlots];   // bracket-relative bin of a candidate: (value - origin) * scale
-    uint32_t hist_bad;            // bit s: a workgroup's LDS queue spilled, block histograms of slot s are incomplete
-    uint32_t below[kSlots];       // keys < lo_key        (atomic, integer => order independent)
-    uint32_t ncand[kSlots];       // keys in [lo_key,hi_key] (atomic)
+    uint32_t below[kSlots];       // keys < lo            (atomic, integer => order independent)
+    uint32_t ncand[kSlots];       // keys in [lo,hi]      (atomic)
     uint32_t ncand_seen[kSlots];  // copy kept for sx_macenko_tile_params
     int32_t use_all;
-    uint32_t fell_back;           // bit s: slot s used the full-tile radix select
-    unsigned long long stamp[16]; // diagnostic: wall_clock64() at stage boundaries of the per-tile kernels
+    uint32_t fell_back;           // bit s: slot s used the whole-group radix select; bit 4+s: candidate radix select
+    unsigned long long stamp[16]; // diagnostic: wall_clock64() at stage boundaries of the per-tile stages
 };
 
 struct Geometry {
     int64_t n_tiles, pixels;      // P = H*W
-    int blocks_per_tile;          // streaming workgroups per tile
-    int chunk;                    // pixels per streaming workgroup
+    int blocks_per_tile;          // work items per tile and stage
+    int vec;                      // 1: 4-pixel packs (16-byte loads), 0: scalar accesses
     int pooled;                   // 1: one group over all tiles (fit), 0: one group per tile
+    int sample_stride, sample_count;   // sample j = pixel j*stride of the group, j < count
 };
 
 struct Workspace {
     GroupState* state;
     double* partial;              // [n_tiles*blocks_per_tile][kMoments]
     uint32_t* cand;               // [groups][kSlots][kCap]
-    uint32_t* block_hist;         // [n_tiles*blocks_per_tile][2][256] bracket-relative histograms of a pass's candidates
-    float* sample_od;             // [groups][3][kSample] OD of the strided sample (written once, read by both per-tile kernels)
+    uint32_t* block_hist;         // [n_tiles*blocks_per_tile][2][256] bracket-relative histograms of a stage's candidates
+    float* sample_od;             // [groups][3][kSample] optical density of the strided sample
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int blocks_per_tile_for(int64_t pixels) {
-    const int64_t chunk = (int64_t)kStreamThreads * 4 * kIters;   // sized for the vector path; the scalar path uses the same count
-    return (int)((pixels + chunk - 1) / chunk);
-}
+static int blocks_per_tile_for(int64_t pixels) { return (int)((pixels + kChunk - 1) / kChunk); }
 
 static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
-    const size_t b = (size_t)blocks_per_tile_for(pixels);
-    size_t total = align_up(sizeof(GroupState) * (size_t)n_tiles, 256);
-    total += align_up(sizeof(double) * kMoments * b * (size_t)n_tiles, 256);
-    total += align_up(sizeof(uint32_t) * kSlots * kCap * (size_t)n_tiles, 256);
-    total += align_up(sizeof(uint32_t) * 2 * 256 * b * (size_t)n_tiles, 256);
-    total += align_up(sizeof(float) * 3 * kSample * (size_t)n_tiles, 256);
+    const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
+    size_t total = align_up(sizeof(GroupState) * n, 256);
+    total += align_up(sizeof(double) * kMoments * b * n, 256);
+    total += align_up(sizeof(uint32_t) * kSlots * kCap * n, 256);
+    total += align_up(sizeof(uint32_t) * 512 * b * n, 256);
+    total += align_up(sizeof(float) * 3 * kSample * n, 256);
     return total;
 }
 
 static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     Workspace w;
     char* p = static_cast<char*>(base);
-    const size_t b = (size_t)blocks_per_tile_for(pixels);
+    const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
     w.state = reinterpret_cast<GroupState*>(p);
-    p += align_up(sizeof(GroupState) * (size_t)n_tiles, 256);
+    p += align_up(sizeof(GroupState) * n, 256);
     w.partial = reinterpret_cast<double*>(p);
-    p += align_up(sizeof(double) * kMoments * b * (size_t)n_tiles, 256);
+    p += align_up(sizeof(double) * kMoments * b * n, 256);
     w.cand = reinterpret_cast<uint32_t*>(p);
-    p += align_up(sizeof(uint32_t) * kSlots * kCap * (size_t)n_tiles, 256);
+    p += align_up(sizeof(uint32_t) * kSlots * kCap * n, 256);
     w.block_hist = reinterpret_cast<uint32_t*>(p);
-    p += align_up(sizeof(uint32_t) * 2 * 256 * b * (size_t)n_tiles, 256);
+    p += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     w.sample_od = reinterpret_cast<float*>(p);
     return w;
 }
+
+// ------------------------------------------------------------------------------------------------
+// data handed from one stage to the next: every stage is its own launch, so a kernel boundary publishes it and
+// plain accesses suffice.  (Measured alternatives, see DESIGN.md: a persistent work-queue kernel with in-launch
+// hand-offs and a 4-way multi-stream split were both slower than seven back-to-back launches.)
+// ------------------------------------------------------------------------------------------------
+template <typename U> __device__ __forceinline__ void put(U* p, U v) { *p = v; }
+template <typename U> __device__ __forceinline__ U get(const U* p) { return *p; }
+
+#define SX_STAMP(st, i) do { if (threadIdx.x == 0) (st).stamp[i] = (unsigned long long)wall_clock64(); } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // per-pixel arithmetic
@@ -123,10 +143,37 @@ __device__ __forceinline__ bool od_selected(const float od[3], bool use_all) {
     return use_all || (fminf(od[0], fminf(od[1], od[2])) >= kBeta);    // torch_backend.py:404-405
 }
 
+// Angle of the plane projection as an order-preserving key.  The reference ranks phi = atan2(t1, t0)
+// (torch_backend.py:418); ranking needs only a monotone function of phi, so pixels carry the "diamond angle"
+//   r = t1 / (|t0| + |t1|);   t0 >= 0: r in [-1,1];   t0 < 0, t1 >= 0: 2 - r in (1,2];   t0 < 0, t1 < 0: -2 - r in [-2,-1)
+// (one v_rcp_f32 instead of a ~40-instruction atan2f).  The two selected keys per tile are turned back into
+// phi by angle_from_key() in double precision; the difference from atan2f of the same pixel is ~1e-7 rad.
+__device__ __forceinline__ float diamond_angle(float t1, float t0) {
+    const float den = fabsf(t0) + fabsf(t1);
+    const float r = den > 0.0f ? t1 * __frcp_rn(den) : 0.0f;
+    return t0 >= 0.0f ? r : (t1 >= 0.0f ? 2.0f - r : -2.0f - r);
+}
+
 __device__ __forceinline__ uint32_t angle_key(const float od[3], const float* __restrict__ v) {
     const float t0 = fmaf(od[2], v[4], fmaf(od[1], v[2], od[0] * v[0]));   // That[:,0]  (:417)
     const float t1 = fmaf(od[2], v[5], fmaf(od[1], v[3], od[0] * v[1]));   // That[:,1]
-    return float_key(atan2f(t1, t0));                                       // :418
+    return float_key(diamond_angle(t1, t0));
+}
+
+__device__ inline float angle_from_key(uint32_t key) {
+    const double d = (double)key_float(key);
+    double x, y;
+    if (d > 1.0) {            // second quadrant: d = 2 - r
+        y = 2.0 - d;
+        x = -(1.0 - y);
+    } else if (d < -1.0) {    // third quadrant: d = -2 - r, r in (-1,0]
+        y = -2.0 - d;
+        x = -(1.0 + y);
+    } else {
+        y = d;
+        x = 1.0 - fabs(d);
+    }
+    return (float)atan2(y, x);
 }
 
 __device__ __forceinline__ void concentration(const float od[3], const float* __restrict__ pinv, float& c0, float& c1) {
@@ -142,66 +189,7 @@ __device__ __forceinline__ void load_od_scalar(const T* __restrict__ images, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1: raw moments of the OD vectors
-// ------------------------------------------------------------------------------------------------
-template <typename T, int V>
-__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, double* __restrict__ partial) {
-    const int64_t tile = blockIdx.x / g.blocks_per_tile;
-    const int chunk_id = blockIdx.x % g.blocks_per_tile;
-    const int64_t p_begin = (int64_t)chunk_id * g.chunk;
-    const int64_t p_end = min(p_begin + g.chunk, g.pixels);
-    const T* img = images + tile * 3 * g.pixels;
-
-    double acc[kMoments];
-#pragma unroll
-    for (int k = 0; k < kMoments; ++k) acc[k] = 0.0;
-
-    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
-        float u[3][V];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
-        // fp32 sums over the V pixels of this pack, fp64 across packs / lanes / workgroups
-        float m[10], a[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) m[k] = a[k] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float od[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
-            const float keep = od_selected(od, false) ? 1.0f : 0.0f;
-            const float pr[10] = {1.0f, od[0], od[1], od[2], od[0] * od[0], od[0] * od[1], od[0] * od[2], od[1] * od[1], od[1] * od[2], od[2] * od[2]};
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                a[k] += pr[k];
-                m[k] = fmaf(keep, pr[k], m[k]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            acc[k] += (double)m[k];
-            acc[10 + k] += (double)a[k];
-        }
-    }
-
-    __shared__ double red[kStreamThreads / kWave][kMoments];
-    const int wave = threadIdx.x / kWave;
-#pragma unroll
-    for (int k = 0; k < kMoments; ++k) {
-        const double s = wave_sum(acc[k]);
-        if (lane_id() == 0) red[wave][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kMoments) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < kStreamThreads / kWave; ++w) s += red[w][threadIdx.x];
-        partial[(int64_t)blockIdx.x * kMoments + threadIdx.x] = s;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// helpers of the per-tile kernels
+// small numerics of the per-tile stages
 // ------------------------------------------------------------------------------------------------
 // One Jacobi rotation in the (p,q) plane of a symmetric 3x3 kept in scalars (r is the third index).
 #define SX_JACOBI_ROTATE(app, aqq, apq, arp, arq, v0p, v0q, v1p, v1q, v2p, v2q)            \
@@ -258,6 +246,38 @@ __device__ void jacobi_eigh3(const double a_in[9], double w[3], double q[9]) {
     q[6] = v20; q[7] = v21; q[8] = v22;
 }
 #undef SX_JACOBI_ROTATE
+
+// Raw moments -> unbiased covariance (torch_backend.py:395-397) -> plane vectors, columns [1,2] of eigh
+// (torch_backend.py:415), sign convention: positive component sum.  mom[0..9] masked set, mom[10..19] all pixels;
+// fewer than 3 masked pixels -> all pixels when allow_fallback (torch_backend.py:409-410).
+__device__ void plane_from_moments(const double* mom, bool allow_fallback, double cov[9], float vecs[6], bool& use_all, unsigned long long& n_sel) {
+    use_all = allow_fallback && mom[0] < 3.0;
+    const double* a = use_all ? mom + 10 : mom;
+    const double cnt = a[0];
+    if (cnt > 1.0) {
+        const double m0 = a[1] / cnt, m1 = a[2] / cnt, m2 = a[3] / cnt, d = cnt - 1.0;
+        cov[0] = (a[4] - a[1] * m0) / d;
+        cov[1] = cov[3] = (a[5] - a[1] * m1) / d;
+        cov[2] = cov[6] = (a[6] - a[1] * m2) / d;
+        cov[4] = (a[7] - a[2] * m1) / d;
+        cov[5] = cov[7] = (a[8] - a[2] * m2) / d;
+        cov[8] = (a[9] - a[3] * m2) / d;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cov[i] = 0.0;
+    }
+    double w[3], q[9];
+    jacobi_eigh3(cov, w, q);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int src = c + 1;
+        const double sum = q[0 * 3 + src] + q[1 * 3 + src] + q[2 * 3 + src];
+        const double sgn = sum < 0.0 ? -1.0 : 1.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) vecs[r * 2 + c] = (float)(sgn * q[r * 3 + src]);
+    }
+    n_sel = (unsigned long long)cnt;
+}
 
 // Angle percentiles -> extreme stain vectors -> HE_source (H before E) -> its (2,3) pseudo-inverse.
 __device__ void stain_vectors_and_pinv(const float* vecs, float phi_lo, float phi_hi, float* he_out, float* pinv_out) {
@@ -329,7 +349,7 @@ __device__ __forceinline__ void bracket_ranks(int m_valid, unsigned long long n_
     hi_r = (long long)ceil(r + 6.0 * sd + 3.0);
 }
 
-// One wave turns a 256-bin histogram and a rank into (digit, rank inside that digit's bin).
+// One wave turns a 256-bin histogram and a rank into (bin, rank inside that bin).
 __device__ __forceinline__ void scan_pick(const uint32_t* hist, unsigned long long rank, uint32_t& digit, unsigned long long& rank_in_bin) {
     const int lane = (int)lane_id();
     const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
@@ -351,12 +371,12 @@ __device__ __forceinline__ void scan_pick(const uint32_t* hist, unsigned long lo
     rank_in_bin = r;
 }
 
-// Bracket-relative bin (0..255) of a key in [lo,hi], linear in the float VALUE the key stands for (key-linear
-// bins would crowd: float keys spend one binade per exponent) and monotone in the key.  scale = 256/(v_hi-v_lo);
-// an open or degenerate bracket gets scale 0 (everything in bin 0 -> the radix paths take over).
-__device__ __forceinline__ uint32_t bin_of(uint32_t key, double lo_value, double scale) {
-    const double d = ((double)key_float(key) - lo_value) * scale;
-    return (uint32_t)fmin(fmax(d, 0.0), 255.0);     // values beyond the range (open brackets) go to the end bins
+// Bracket-relative bin (0..255) of a key, linear in the float VALUE the key stands for (key-linear bins would
+// crowd: float keys spend one binade per exponent) and monotone in the key.  Values beyond the range
+// (open brackets) go to the end bins; a degenerate range gets scale 0 (everything in bin 0 -> radix paths).
+__device__ __forceinline__ uint32_t bin_of(uint32_t key, double origin, double scale) {
+    const double d = ((double)key_float(key) - origin) * scale;
+    return (uint32_t)fmin(fmax(d, 0.0), 255.0);
 }
 __device__ __forceinline__ double bin_origin_for(uint32_t lo) { return (double)key_float(lo); }
 __device__ __forceinline__ double bin_scale_for(uint32_t lo, uint32_t hi) {
@@ -364,103 +384,44 @@ __device__ __forceinline__ double bin_scale_for(uint32_t lo, uint32_t hi) {
     return (span > 0.0 && span < 1e300) ? 256.0 / span : 0.0;
 }
 
-// Exact r-th smallest (0-based, ties by index) of a short LDS list by rank counting; the owner writes *out.
+// Exact r-th smallest (0-based, ties by index) of a short LDS list by rank counting: each wave takes every
+// n_waves-th element, its lanes split the comparisons and add their counts up.  Whole workgroup calls it.
 __device__ __forceinline__ void rank_pick(const uint32_t* list, uint32_t n, unsigned long long r, uint32_t* out) {
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t wave = threadIdx.x / kWave, n_waves = blockDim.x / kWave, lane = lane_id();
+    for (uint32_t i = wave; i < n; i += n_waves) {
         const uint32_t k = list[i];
         uint32_t c = 0;
-#pragma unroll 16
-        for (uint32_t t = 0; t < n; ++t) {
+        for (uint32_t t = lane; t < n; t += kWave) {
             const uint32_t x = list[t];
             c += (x < k || (x == k && t < i)) ? 1u : 0u;
         }
-        if (c == r) *out = k;
+        c = wave_sum_u32(c);
+        if (lane == 0 && c == r) *out = k;
     }
 }
 
-struct SelectJob {
-    uint32_t count;              // 0: nothing to select
-    unsigned long long rank;     // 0-based, among the keys that lie in [lo,hi]
-    uint32_t lo, hi;             // keys outside [lo,hi] are ignored
+// LDS scratch of a per-tile stage (one workgroup).
+struct TileScratch {
+    uint32_t keys[kSample];               // keys of the sample (one key set at a time)
+    uint32_t hist[2][256];
+    uint32_t list[4][kShortList];
+    double mom[kMoments];
+    double stage[12][kMoments];
+    unsigned long long rank_in_bin[4], radix_rank, n_sel;
+    uint32_t bin[4], count[4], result[4];
+    uint32_t range_lo, range_hi, radix_digit;
+    int valid;
+    float coef[6];
+    int flag;
 };
 
-template <int R> struct SelectShared {
-    uint32_t hist[R][256];
-    unsigned long long rank[R];
-    uint32_t digit[R];
-};
-
-// R exact order statistics at once (whole workgroup, >= R waves) over keys held in REGISTERS: every
-// thread owns up to KPT keys of each of NSETS key sets, job r selects in set set_of[r].  Radix rounds of
-// up to 8 bits over key - lo, starting at the top bit of hi - lo, so the first round already spreads
-// the keys over the whole LDS histogram (byte-aligned digits of clustered float keys would pile onto a
-// few bins and serialise the LDS atomics).  One histogram per job; wave j resolves job j.
-template <int R, int NSETS, int KPT>
-__device__ void multi_select(const uint32_t (&keys)[NSETS][KPT], const int (&n_mine)[NSETS], const int (&set_of)[R], const SelectJob (&job)[R],
-                             uint32_t (&result)[R], SelectShared<R>* sh) {
-    unsigned long long found[R];   // value of (key - lo) >> s_prev fixed so far
-    int s_prev[R];                 // bits of key - lo still undetermined
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t span = job[r].hi - job[r].lo;
-        found[r] = 0;
-        s_prev[r] = (job[r].count == 0 || span == 0) ? 0 : 32 - __clz(span);
-        if (threadIdx.x == 0) sh->rank[r] = job[r].rank;
-    }
-    const int wave = threadIdx.x / kWave;
-    for (;;) {
-        bool any = false;
-#pragma unroll
-        for (int r = 0; r < R; ++r) any |= s_prev[r] > 0;
-        if (!any) break;
-        for (int t = threadIdx.x; t < R * 256; t += blockDim.x) (&sh->hist[0][0])[t] = 0;
-        __syncthreads();
-        int s_now[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            s_now[r] = s_prev[r] > 8 ? s_prev[r] - 8 : 0;
-            if (s_prev[r] <= 0) continue;
-            const uint32_t lo = job[r].lo, hi = job[r].hi;
-            const unsigned long long base = found[r] << (s_prev[r] - s_now[r]);
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t k = keys[set_of[r]][i];
-                if (i >= n_mine[set_of[r]] || k < lo || k > hi) continue;
-                const unsigned long long kp = (unsigned long long)(k - lo);
-                if ((kp >> s_prev[r]) == found[r]) atomicAdd(&sh->hist[r][(uint32_t)((kp >> s_now[r]) - base)], 1u);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (wave == r && s_prev[r] > 0) {
-                uint32_t d;
-                unsigned long long rb;
-                scan_pick(sh->hist[r], sh->rank[r], d, rb);
-                if (lane_id() == 0) {
-                    sh->digit[r] = d;
-                    sh->rank[r] = rb;
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (s_prev[r] <= 0) continue;
-            found[r] = (found[r] << (s_prev[r] - s_now[r])) + sh->digit[r];
-            s_prev[r] = s_now[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) result[r] = job[r].lo + (uint32_t)found[r];
-}
-
-// Slow path: exact rank-th smallest of the valid keys produced by key_at(i), i in [0,count), recomputed
-// from the pixels in every round.  Whole workgroup.
+// Exact rank-th smallest (0-based) of the valid keys produced by key_at(i), i in [0,count): four 8-bit radix
+// rounds, keys recomputed/re-read in every round.  Slow path, whole workgroup.
 template <class KeyAt>
-__device__ uint32_t radix_select_stream(unsigned long long count, unsigned long long rank, KeyAt key_at, SelectShared<1>* sh) {
+__device__ uint32_t radix_select_stream(unsigned long long count, unsigned long long rank, KeyAt key_at, TileScratch* sh) {
     uint32_t prefix = 0, mask = 0;
-    if (threadIdx.x == 0) sh->rank[0] = rank;
+    __syncthreads();
+    if (threadIdx.x == 0) sh->radix_rank = rank;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int t = threadIdx.x; t < 256; t += blockDim.x) sh->hist[0][t] = 0;
         __syncthreads();
@@ -472,17 +433,129 @@ __device__ uint32_t radix_select_stream(unsigned long long count, unsigned long 
         if (threadIdx.x < kWave) {
             uint32_t d;
             unsigned long long rb;
-            scan_pick(sh->hist[0], sh->rank[0], d, rb);
+            scan_pick(sh->hist[0], sh->radix_rank, d, rb);
             if (lane_id() == 0) {
-                sh->digit[0] = d;
-                sh->rank[0] = rb;
+                sh->radix_digit = d;
+                sh->radix_rank = rb;
             }
         }
         __syncthreads();
-        prefix |= sh->digit[0] << shift;
+        prefix |= sh->radix_digit << shift;
         mask |= 0xFFu << shift;
+        __syncthreads();
     }
     return prefix;
+}
+
+// Brackets for up to two wanted ranks (k0[0..n_ranks)) of n_total keys from the kSample sample keys in
+// sh->keys (invalid entries are 0xFFFFFFFF).  Two levels: one 256-bin value-linear histogram of the sample over
+// [min,max], one wave per wanted sample rank picks its bin, the keys of that bin are gathered and the exact
+// element found by rank counting (a crowded bin falls back to radix rounds).  Outputs per wanted rank: the
+// bracket keys and the (origin, scale) of the bracket-relative bins used for the candidates.
+__device__ void sample_brackets(TileScratch* sh, int n_ranks, unsigned long long n_total, const unsigned long long* k0, uint32_t* lo, uint32_t* hi,
+                                double* bin_origin, double* bin_scale) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sh->range_lo = 0xFFFFFFFFu;
+        sh->range_hi = 0u;
+        sh->valid = 0;
+    }
+    if (threadIdx.x < 4) sh->count[threadIdx.x] = 0;
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) sh->hist[0][t] = 0;
+    __syncthreads();
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u, valid = 0;
+    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+        const uint32_t k = sh->keys[j];
+        if (k != 0xFFFFFFFFu) {
+            mn = min(mn, k);
+            mx = max(mx, k);
+            ++valid;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_down(mn, off, kWave));
+        mx = max(mx, (uint32_t)__shfl_down(mx, off, kWave));
+    }
+    valid = wave_sum_u32(valid);
+    if (lane_id() == 0) {
+        atomicMin(&sh->range_lo, mn);
+        atomicMax(&sh->range_hi, mx);
+        if (valid) atomicAdd(&sh->valid, (int)valid);
+    }
+    __syncthreads();
+    const int m_valid = sh->valid;
+    const uint32_t set_lo = sh->range_lo, set_hi = sh->range_hi;
+    const double origin = bin_origin_for(set_lo), scale = bin_scale_for(set_lo, set_hi);
+    bool want[4] = {false, false, false, false};
+    unsigned long long rank[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s >= n_ranks) continue;
+        long long lo_r, hi_r;
+        bracket_ranks(m_valid, n_total, k0[s], lo_r, hi_r);
+        want[2 * s] = m_valid > 0 && lo_r >= 0;
+        want[2 * s + 1] = m_valid > 0 && hi_r < m_valid;
+        rank[2 * s] = (unsigned long long)(lo_r < 0 ? 0 : lo_r);
+        rank[2 * s + 1] = (unsigned long long)(hi_r < 0 ? 0 : hi_r);
+    }
+    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+        const uint32_t k = sh->keys[j];
+        if (k != 0xFFFFFFFFu) atomicAdd(&sh->hist[0][bin_of(k, origin, scale)], 1u);
+    }
+    __syncthreads();
+    const int wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (wave == q && want[q]) {
+            uint32_t b;
+            unsigned long long rb;
+            scan_pick(sh->hist[0], rank[q], b, rb);
+            if (lane_id() == 0) {
+                sh->bin[q] = b;
+                sh->rank_in_bin[q] = rb;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+        const uint32_t k = sh->keys[j];
+        if (k == 0xFFFFFFFFu) continue;
+        const uint32_t b = bin_of(k, origin, scale);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (want[q] && b == sh->bin[q]) {
+                const uint32_t at = atomicAdd(&sh->count[q], 1u);
+                if (at < (uint32_t)kShortList) sh->list[q][at] = k;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t res[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!want[q]) continue;
+        if (sh->count[q] <= (uint32_t)kShortList) {
+            rank_pick(sh->list[q], sh->count[q], sh->rank_in_bin[q], &sh->result[q]);
+            __syncthreads();
+            res[q] = sh->result[q];
+        } else {    // crowded bin (uniform decision: the count lives in LDS)
+            const uint32_t* keys = sh->keys;
+            res[q] = radix_select_stream((unsigned long long)kSample, rank[q], [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return k != 0xFFFFFFFFu; }, sh);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s >= n_ranks) continue;
+        lo[s] = want[2 * s] ? res[2 * s] : 0u;
+        hi[s] = want[2 * s + 1] ? res[2 * s + 1] : 0xFFFFFFFFu;
+        // candidate bins span the bracket; an open side is bounded by the sample's extreme (the few keys beyond it
+        // fall into the end bin)
+        const uint32_t range_lo = want[2 * s] ? res[2 * s] : set_lo, range_hi = want[2 * s + 1] ? res[2 * s + 1] : set_hi;
+        bin_origin[s] = bin_origin_for(range_lo);
+        bin_scale[s] = m_valid > 0 ? bin_scale_for(range_lo, range_hi) : 0.0;
+    }
+    __syncthreads();
 }
 
 // Pixel walker of one group: tile-local for transform, all tiles for the pooled fit.
@@ -509,356 +582,135 @@ __device__ __forceinline__ GroupPixels group_pixels(const Geometry& g, int group
     return gp;
 }
 
-// j-th of m evenly spaced sample positions in [0,count): floor(j*count/m); m is kSample (a power of two)
-// whenever count >= kSample, so the division is a shift there.
-__device__ __forceinline__ int64_t sample_position(int j, int m, int64_t count) {
-    const unsigned long long prod = (unsigned long long)j * (unsigned long long)count;
-    return (int64_t)(m == kSample ? prod / (unsigned)kSample : prod / (unsigned long long)m);
-}
-
-constexpr int kSamplePerThread = kSample / kGroupThreads;   // 4 sample keys per thread, kept in registers
-
-constexpr int kShortList = 1024;   // keys of one histogram bin gathered for rank counting
-
-struct SampleShared {
-    union {
-        SelectShared<4> sel;                 // radix fallback
-        struct {
-            uint32_t hist[2][256];           // one histogram per key set
-            uint32_t list[4][kShortList];    // keys of the four picked bins
-        } two;
-    };
-    uint32_t lo[2], hi[2];
-    uint32_t bin[4], count[4], result[4];
-    unsigned long long rank_in_bin[4];
-    int valid;
+// ------------------------------------------------------------------------------------------------
+// streaming stage S1: raw moments of the OD vectors of one work item (+ the sample's OD on the way)
+// ------------------------------------------------------------------------------------------------
+template <int TPB> struct StatsScratch {
+    double red[TPB / kWave][kMoments];
 };
 
-// Brackets for two wanted ranks (k0[0], k0[1]) in key sets A and B from the rank statistics of a
-// kSample-key sample spread over the workgroup's registers (invalid entries are 0xFFFFFFFF).
-// Four sample order statistics (two ranks per key set) in two levels: one 256-bin histogram per key set over
-// [min,max] (a single round of LDS atomics), one wave per rank picks its bin, the keys of that bin
-// are gathered and the exact element is found by rank counting.  A crowded bin (> kShortList keys)
-// falls back to the radix rounds of multi_select.
-template <int NSETS>
-__device__ void sample_brackets(const uint32_t (&keys)[NSETS][kSamplePerThread], unsigned long long n_total, const unsigned long long (&k0)[2], uint32_t (&lo)[2],
-                                uint32_t (&hi)[2], double (&bin_origin)[2], double (&bin_scale)[2], SampleShared* sh) {
-    if (threadIdx.x < 2) {
-        sh->lo[threadIdx.x] = 0xFFFFFFFFu;
-        sh->hi[threadIdx.x] = 0u;
-    }
-    if (threadIdx.x < 4) sh->count[threadIdx.x] = 0;
-    if (threadIdx.x == 0) sh->valid = 0;
-    for (int t = threadIdx.x; t < 2 * 256; t += blockDim.x) (&sh->two.hist[0][0])[t] = 0;
-    __syncthreads();
-    int valid = 0;
-#pragma unroll
-    for (int set = 0; set < NSETS; ++set) {
-        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-#pragma unroll
-        for (int i = 0; i < kSamplePerThread; ++i) {
-            const uint32_t k = keys[set][i];
-            if (k != 0xFFFFFFFFu) {
-                mn = min(mn, k);
-                mx = max(mx, k);
-                if (set == 0) ++valid;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mn = min(mn, (uint32_t)__shfl_down(mn, off, kWave));
-            mx = max(mx, (uint32_t)__shfl_down(mx, off, kWave));
-        }
-        if (lane_id() == 0) {
-            atomicMin(&sh->lo[set], mn);
-            atomicMax(&sh->hi[set], mx);
-        }
-    }
-    valid = (int)wave_sum_u32((uint32_t)valid);
-    if (lane_id() == 0 && valid) atomicAdd(&sh->valid, valid);
-    __syncthreads();
-    const int m_valid = sh->valid;
-    long long lo_r[2], hi_r[2];
-    bool want[4];
-    unsigned long long rank[4];
-    uint32_t set_lo[NSETS], set_hi[NSETS];
-    double origin[NSETS], scale[NSETS];
-#pragma unroll
-    for (int set = 0; set < NSETS; ++set) {
-        set_lo[set] = sh->lo[set];
-        set_hi[set] = sh->hi[set];
-        origin[set] = bin_origin_for(set_lo[set]);
-        scale[set] = bin_scale_for(set_lo[set], set_hi[set]);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bracket_ranks(m_valid, n_total, k0[s], lo_r[s], hi_r[s]);
-        want[2 * s] = m_valid > 0 && lo_r[s] >= 0;
-        want[2 * s + 1] = m_valid > 0 && hi_r[s] < m_valid;
-        rank[2 * s] = (unsigned long long)(lo_r[s] < 0 ? 0 : lo_r[s]);
-        rank[2 * s + 1] = (unsigned long long)(hi_r[s] < 0 ? 0 : hi_r[s]);
-    }
-    // level 1: histograms
-#pragma unroll
-    for (int set = 0; set < NSETS; ++set)
-#pragma unroll
-        for (int i = 0; i < kSamplePerThread; ++i) {
-            const uint32_t k = keys[set][i];
-            if (k != 0xFFFFFFFFu) atomicAdd(&sh->two.hist[set][bin_of(k, origin[set], scale[set])], 1u);
-        }
-    __syncthreads();
-    const int wave = threadIdx.x / kWave;
-    if (wave < 4 && want[wave < 4 ? wave : 0]) {
-        const int set = (wave >> 1) ? NSETS - 1 : 0;
-        uint32_t b;
-        unsigned long long rb;
-        scan_pick(sh->two.hist[set], rank[wave], b, rb);
-        if (lane_id() == 0) {
-            sh->bin[wave] = b;
-            sh->rank_in_bin[wave] = rb;
-        }
-    }
-    __syncthreads();
-    // level 2: gather the picked bins, rank-count inside them
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (!want[j]) continue;
-        const int set = (j >> 1) ? NSETS - 1 : 0;
-        const uint32_t b = sh->bin[j];
-#pragma unroll
-        for (int i = 0; i < kSamplePerThread; ++i) {
-            const uint32_t k = keys[set][i];
-            if (k != 0xFFFFFFFFu && bin_of(k, origin[set], scale[set]) == b) {
-                const uint32_t idx = atomicAdd(&sh->count[j], 1u);
-                if (idx < (uint32_t)kShortList) sh->two.list[j][idx] = k;
-            }
-        }
-    }
-    __syncthreads();
-    bool crowded = false;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (!want[j]) continue;
-        if (sh->count[j] > (uint32_t)kShortList) crowded = true;
-        else rank_pick(sh->two.list[j], sh->count[j], sh->rank_in_bin[j], &sh->result[j]);
-    }
-    __syncthreads();
-    uint32_t res[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) res[j] = sh->result[j];
-    if (crowded) {   // uniform: the counts live in LDS
-        __syncthreads();
-        SelectJob job[4];
-        const int set_of[4] = {0, 0, NSETS - 1, NSETS - 1};
-        int n_mine[NSETS];
-#pragma unroll
-        for (int set = 0; set < NSETS; ++set) n_mine[set] = kSamplePerThread;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int set = (j >> 1) ? NSETS - 1 : 0;
-            job[j] = SelectJob{want[j] ? (uint32_t)kSample : 0u, rank[j], set_lo[set], set_hi[set]};
-        }
-        multi_select<4, NSETS, kSamplePerThread>(keys, n_mine, set_of, job, res, &sh->sel);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int set = s ? NSETS - 1 : 0;
-        lo[s] = want[2 * s] ? res[2 * s] : 0u;
-        hi[s] = want[2 * s + 1] ? res[2 * s + 1] : 0xFFFFFFFFu;
-        // candidate bins span the bracket; an open side is bounded by the sample's extreme (the few keys beyond it
-        // fall into the end bin)
-        const uint32_t range_lo = want[2 * s] ? res[2 * s] : set_lo[set], range_hi = want[2 * s + 1] ? res[2 * s + 1] : set_hi[set];
-        bin_origin[s] = bin_origin_for(range_lo);
-        bin_scale[s] = m_valid > 0 ? bin_scale_for(range_lo, range_hi) : 0.0;
-    }
-}
-
-// Raw moments -> unbiased covariance (torch_backend.py:395-397) -> plane vectors, columns [1,2] of eigh
-// (torch_backend.py:415), sign convention: positive component sum.  mom[0..9] masked set, mom[10..19] all pixels;
-// fewer than 3 masked pixels -> all pixels when allow_fallback (torch_backend.py:409-410).
-__device__ void plane_from_moments(const double* mom, bool allow_fallback, double cov[9], float vecs[6], bool& use_all, unsigned long long& n_sel) {
-    use_all = allow_fallback && mom[0] < 3.0;
-    const double* a = use_all ? mom + 10 : mom;
-    const double cnt = a[0];
-    if (cnt > 1.0) {
-        const double m0 = a[1] / cnt, m1 = a[2] / cnt, m2 = a[3] / cnt, d = cnt - 1.0;
-        cov[0] = (a[4] - a[1] * m0) / d;
-        cov[1] = cov[3] = (a[5] - a[1] * m1) / d;
-        cov[2] = cov[6] = (a[6] - a[1] * m2) / d;
-        cov[4] = (a[7] - a[2] * m1) / d;
-        cov[5] = cov[7] = (a[8] - a[2] * m2) / d;
-        cov[8] = (a[9] - a[3] * m2) / d;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) cov[i] = 0.0;
-    }
-    double w[3], q[9];
-    jacobi_eigh3(cov, w, q);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int src = c + 1;
-        const double sum = q[0 * 3 + src] + q[1 * 3 + src] + q[2 * 3 + src];
-        const double sgn = sum < 0.0 ? -1.0 : 1.0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) vecs[r * 2 + c] = (float)(sgn * q[r * 3 + src]);
-    }
-    n_sel = (unsigned long long)cnt;
-}
-
-// ------------------------------------------------------------------------------------------------
-// per-tile kernel A: moments -> covariance -> plane vectors; angle brackets from the sample
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restrict__ images, Geometry g, Workspace ws, int allow_fallback) {
-    const int group = blockIdx.x;
-    GroupState& st = ws.state[group];
-    const GroupPixels gp = group_pixels(g, group);
-    __shared__ double mom[kMoments];
-    __shared__ SampleShared sample_sh;
-    __shared__ float v_s[6];
-    __shared__ int use_all_s;
-    __shared__ unsigned long long n_sel_s;
-
-    // strided sample of the group's pixels: issue the scattered loads first, they land while the moments are
-    // summed and the covariance is diagonalised
-    const int m = (int)min((int64_t)kSample, gp.count);
-    float sample[kSamplePerThread][3];
-#pragma unroll
-    for (int i = 0; i < kSamplePerThread; ++i) {
-        const int j = threadIdx.x + i * kGroupThreads;
-        sample[i][0] = sample[i][1] = sample[i][2] = 0.0f;
-        if (j < m) {
-            int64_t tile, p;
-            gp.locate(sample_position(j, m, gp.count), tile, p);
-            load_od_scalar<T>(images, g.pixels, tile, p, sample[i]);
-        }
-    }
-    SX_STAMP(st, 0);
-    {
-        // fixed-order (deterministic) sum of the workgroup partials: lanes fetch them in parallel, one thread
-        // per moment adds them in index order
-        __shared__ double stage[32][kMoments];
-        const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
-        const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
-        double running = 0.0;
-        for (int64_t b0 = 0; b0 < nblk; b0 += 32) {
-            const int live = (int)min((int64_t)32, nblk - b0);
-            if ((int)threadIdx.x < live * kMoments) stage[threadIdx.x / kMoments][threadIdx.x % kMoments] = ws.partial[(first + b0) * kMoments + threadIdx.x];
-            __syncthreads();
-            if (threadIdx.x < kMoments)
-                for (int b = 0; b < live; ++b) running += stage[b][threadIdx.x];
-            __syncthreads();
-        }
-        if (threadIdx.x < kMoments) mom[threadIdx.x] = running;
-    }
-    __syncthreads();
-
-    SX_STAMP(st, 1);
-    if (threadIdx.x == 0) {
-        double cov[9];
-        bool use_all;
-        unsigned long long n_sel_local;
-        plane_from_moments(mom, allow_fallback != 0, cov, v_s, use_all, n_sel_local);
-        const double cnt = (double)n_sel_local;
-        use_all_s = use_all ? 1 : 0;
-        n_sel_s = (unsigned long long)cnt;
-#pragma unroll
-        for (int k = 0; k < kMoments; ++k) st.mom[k] = mom[k];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) st.cov[i] = cov[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) st.vecs[i] = v_s[i];
-        st.use_all = use_all_s;
-        st.n_sel = n_sel_s;
-        st.fell_back = 0;
-        st.hist_bad = 0;
-#pragma unroll
-        for (int s = 0; s < kSlots; ++s) st.below[s] = st.ncand[s] = 0;
-    }
-    __syncthreads();
-
-    SX_STAMP(st, 2);
-    // angle keys of the selected sample pixels; the sample's OD is kept for the concentration brackets
-    const bool use_all = use_all_s != 0;
-    float v[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = v_s[i];
-    uint32_t keys[1][kSamplePerThread];
+template <typename T, int V, int TPB>
+__device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh) {
+    const int64_t p_begin = (int64_t)chunk_id * kChunk;
+    const int64_t p_end = min(p_begin + (int64_t)kChunk, g.pixels);
+    const T* img = images + tile * 3 * g.pixels;
+    const int group = g.pooled ? 0 : (int)tile;
     float* sample_out = ws.sample_od + (size_t)group * 3 * kSample;
+    const uint32_t group_offset = g.pooled ? (uint32_t)(tile * g.pixels) : 0u;      // position of this tile inside its group (< 2^32)
+    const uint32_t stride = (uint32_t)g.sample_stride, sample_count = (uint32_t)g.sample_count;
+
+    // products and the sums over this lane's 32 pixels in fp32, everything beyond in fp64: the fp32 rounding is
+    // unbiased and averages out over the tile (~4e-9 on a covariance entry, measured against the fp64 covariance
+    // in the tests), the cancellation in sum(xy) - sum(x)*mean(y) happens in fp64
+    float m[10], a[10];
 #pragma unroll
-    for (int i = 0; i < kSamplePerThread; ++i) {
-        const int j = threadIdx.x + i * kGroupThreads;
-        keys[0][i] = (j < m && od_selected(sample[i], use_all)) ? angle_key(sample[i], v) : 0xFFFFFFFFu;
+    for (int k = 0; k < 10; ++k) m[k] = a[k] = 0.0f;
+    const uint32_t mask = stride - 1u;          // stride is a power of two
+    const int shift = 31 - __clz((int)stride);
+
+    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
+        float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) sample_out[c * kSample + j] = sample[i][c];
-    }
-    const unsigned long long n_sel = n_sel_s;
-    const unsigned long long k0[2] = {nearest_rank_index(1.0, n_sel), nearest_rank_index(99.0, n_sel)};   // alpha = 1 (torch_backend.py:421-422)
-    uint32_t lo[2], hi[2];
-    double b_origin[2], b_scale[2];
-    SX_STAMP(st, 3);
-    sample_brackets<1>(keys, n_sel, k0, lo, hi, b_origin, b_scale, &sample_sh);
-    SX_STAMP(st, 4);
-    if (threadIdx.x == 0) {
+        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+        const uint32_t gpos = group_offset + (uint32_t)p;      // position inside the group; samples sit at multiples of stride
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            st.rank[s] = k0[s];
-            st.lo_key[s] = lo[s];
-            st.hi_key[s] = hi[s];
-            st.bin_origin[s] = b_origin[s];
-            st.bin_scale[s] = b_scale[s];
+        for (int i = 0; i < V; ++i) {
+            float od[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
+            const float keep = od_selected(od, false) ? 1.0f : 0.0f;
+            const float pr[10] = {1.0f, od[0], od[1], od[2], od[0] * od[0], od[0] * od[1], od[0] * od[2], od[1] * od[1], od[1] * od[2], od[2] * od[2]};
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                a[k] += pr[k];
+                m[k] = fmaf(keep, pr[k], m[k]);
+            }
+            if (((gpos + (uint32_t)i) & mask) == 0u) {
+                const uint32_t j = (gpos + (uint32_t)i) >> shift;
+                if (j < sample_count) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od[c]);
+                }
+            }
         }
+    }
+    double acc[kMoments];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        acc[k] = (double)m[k];
+        acc[10 + k] = (double)a[k];
+    }
+
+    const int wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane_id() == 0) sh->red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMoments) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < TPB / kWave; ++w) s += sh->red[w][threadIdx.x];
+        put(&ws.partial[item * kMoments + threadIdx.x], s);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// streaming pass: count keys below each bracket, gather the keys inside it
+// streaming stages S2 / S3: count keys below each bracket, gather + histogram the keys inside it
 //   kConc == false: slots 0,1 share the angle key of the selected pixels
 //   kConc == true : slots 2,3 use the two concentrations of every pixel
-// Candidates are first queued in LDS; one global atomic per workgroup and slot reserves their place.
+// Candidates are queued in LDS; after every kPhasePixels pixels the queues (which therefore cannot overflow)
+// move to the tile's candidate buffers with ONE global atomic per slot.
 // ------------------------------------------------------------------------------------------------
-constexpr int kLocalCap = 4096;        // LDS queue per slot = pixels a workgroup handles between two flushes
-
-struct LocalQueue {
+template <int TPB> struct BracketScratch {
+    static constexpr int kPhase = TPB * 4 > kPhasePixels ? TPB * 4 : kPhasePixels;   // at least one sweep of the workgroup
     uint32_t count[2];
     uint32_t base[2];
-    uint32_t keys[2][kLocalCap];
-    uint32_t hist[2][256];        // bracket-relative histogram of everything this workgroup queued
+    uint32_t keys[2][kPhase];
+    uint32_t hist[2][256];        // bracket-relative histogram of everything this work item queued
+    uint32_t red[2][TPB / kWave];
 };
 
-template <typename T, int V, bool kConc>
-__global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
-    const int64_t tile = blockIdx.x / g.blocks_per_tile;
-    const int chunk_id = blockIdx.x % g.blocks_per_tile;
+__device__ __forceinline__ void load_record(const StageRecord* rec, StageRecord& out) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out.coef[i] = get(&rec->coef[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        out.scale[i] = get(&rec->scale[i]);
+        out.lo[i] = get(&rec->lo[i]);
+        out.hi[i] = get(&rec->hi[i]);
+        out.bin_origin[i] = get(&rec->bin_origin[i]);
+        out.bin_scale[i] = get(&rec->bin_scale[i]);
+    }
+    out.use_all = get(&rec->use_all);
+}
+
+template <typename T, int V, bool kConc, int TPB>
+__device__ void bracket_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, BracketScratch<TPB>* sh) {
+    constexpr int kPhase = BracketScratch<TPB>::kPhase;
     const int group = g.pooled ? 0 : (int)tile;
     GroupState& st = ws.state[group];
     constexpr int s0 = kConc ? 2 : 0;
-    const int64_t p_begin = (int64_t)chunk_id * g.chunk;
-    const int64_t p_end = min(p_begin + g.chunk, g.pixels);
+    const int64_t p_begin = (int64_t)chunk_id * kChunk;
+    const int64_t p_end = min(p_begin + (int64_t)kChunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
 
-    __shared__ LocalQueue queue;
-    __shared__ uint32_t red[2][kStreamThreads / kWave];
-    if (threadIdx.x < 2) queue.count[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < 512; i += kStreamThreads) (&queue.hist[0][0])[i] = 0;
+    StageRecord rec;
+    load_record(&st.rec[kConc ? 1 : 0], rec);
+    if (threadIdx.x < 2) sh->count[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 512; i += TPB) (&sh->hist[0][0])[i] = 0;
     __syncthreads();
 
-    float coef[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) coef[i] = kConc ? st.pinv[i] : st.vecs[i];
-    const bool use_all = kConc ? true : (st.use_all != 0);
-    const uint32_t lo_a = st.lo_key[s0], hi_a = st.hi_key[s0], lo_b = st.lo_key[s0 + 1], hi_b = st.hi_key[s0 + 1];
-    const double scale_a = st.bin_scale[s0], scale_b = st.bin_scale[s0 + 1], origin_a = st.bin_origin[s0], origin_b = st.bin_origin[s0 + 1];
+    const bool use_all = kConc ? true : (rec.use_all != 0);
+    const uint32_t lo_a = rec.lo[0], hi_a = rec.hi[0], lo_b = rec.lo[1], hi_b = rec.hi[1];
     uint32_t* cand_a = ws.cand + ((size_t)group * kSlots + s0) * kCap;
     uint32_t* cand_b = cand_a + kCap;
     uint32_t below_a = 0, below_b = 0;
 
-    // The chunk is walked in phases of kLocalCap pixels; after each phase the LDS queues (which therefore
-    // cannot overflow) are moved to the tile's candidate buffers with ONE global atomic per slot.
-    constexpr int kPhasePixels = kLocalCap;
-    for (int64_t phase_begin = p_begin; phase_begin < p_end; phase_begin += kPhasePixels) {
-        const int64_t phase_end = min(phase_begin + kPhasePixels, p_end);
-        for (int64_t p = phase_begin + (int64_t)threadIdx.x * V; p < phase_end; p += (int64_t)kStreamThreads * V) {
+    for (int64_t phase_begin = p_begin; phase_begin < p_end; phase_begin += kPhase) {
+        const int64_t phase_end = min(phase_begin + (int64_t)kPhase, p_end);
+        for (int64_t p = phase_begin + (int64_t)threadIdx.x * V; p < phase_end; p += (int64_t)TPB * V) {
             float u[3][V];
 #pragma unroll
             for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
@@ -871,354 +723,78 @@ __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __rest
                 uint32_t key_a, key_b;
                 if constexpr (kConc) {
                     float c0, c1;
-                    concentration(od, coef, c0, c1);
+                    concentration(od, rec.coef, c0, c1);
                     key_a = float_key(c0);
                     key_b = float_key(c1);
                 } else {
-                    key_a = key_b = angle_key(od, coef);
+                    key_a = key_b = angle_key(od, rec.coef);
                 }
                 below_a += (valid && key_a < lo_a) ? 1u : 0u;
                 below_b += (valid && key_b < lo_b) ? 1u : 0u;
-                if (valid && key_a >= lo_a && key_a <= hi_a) queue.keys[0][atomicAdd(&queue.count[0], 1u)] = key_a;
-                if (valid && key_b >= lo_b && key_b <= hi_b) queue.keys[1][atomicAdd(&queue.count[1], 1u)] = key_b;
+                if (valid && key_a >= lo_a && key_a <= hi_a) sh->keys[0][atomicAdd(&sh->count[0], 1u)] = key_a;
+                if (valid && key_b >= lo_b && key_b <= hi_b) sh->keys[1][atomicAdd(&sh->count[1], 1u)] = key_b;
             }
         }
         __syncthreads();
         if (threadIdx.x < 2) {
-            const uint32_t n_local = queue.count[threadIdx.x];
-            queue.base[threadIdx.x] = n_local ? atomicAdd(&st.ncand[s0 + threadIdx.x], n_local) : 0u;
+            const uint32_t n_local = sh->count[threadIdx.x];
+            sh->base[threadIdx.x] = n_local ? atomicAdd(&st.ncand[s0 + threadIdx.x], n_local) : 0u;
         }
         __syncthreads();
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             uint32_t* dst = which == 0 ? cand_a : cand_b;
-            const uint32_t n_local = queue.count[which], base = queue.base[which];
-            const double origin = which == 0 ? origin_a : origin_b, scale = which == 0 ? scale_a : scale_b;
-            for (uint32_t i = threadIdx.x; i < n_local; i += kStreamThreads) {
-                const uint32_t key = queue.keys[which][i];
-                if (base + i < (uint32_t)kCap) dst[base + i] = key;
-                atomicAdd(&queue.hist[which][bin_of(key, origin, scale)], 1u);
+            const uint32_t n_local = sh->count[which], base = sh->base[which];
+            const double origin = rec.bin_origin[which], scale = rec.bin_scale[which];
+            for (uint32_t i = threadIdx.x; i < n_local; i += TPB) {
+                const uint32_t key = sh->keys[which][i];
+                if (base + i < (uint32_t)kCap) put(&dst[base + i], key);
+                atomicAdd(&sh->hist[which][bin_of(key, origin, scale)], 1u);
             }
         }
         __syncthreads();
-        if (threadIdx.x < 2) queue.count[threadIdx.x] = 0;
+        if (threadIdx.x < 2) sh->count[threadIdx.x] = 0;
         __syncthreads();
     }
 
     const uint32_t wa = wave_sum_u32(below_a), wb = wave_sum_u32(below_b);
     if (lane_id() == 0) {
-        red[0][threadIdx.x / kWave] = wa;
-        red[1][threadIdx.x / kWave] = wb;
+        sh->red[0][threadIdx.x / kWave] = wa;
+        sh->red[1][threadIdx.x / kWave] = wb;
     }
     __syncthreads();
     if (threadIdx.x < 2) {
         uint32_t sum = 0;
 #pragma unroll
-        for (int w = 0; w < kStreamThreads / kWave; ++w) sum += red[threadIdx.x][w];
+        for (int w = 0; w < TPB / kWave; ++w) sum += sh->red[threadIdx.x][w];
         if (sum) atomicAdd(&st.below[s0 + threadIdx.x], sum);
     }
-    // the workgroup's histograms are stored -- not added -- so the per-tile kernel can sum them in a fixed
-    // order without any global atomic
-    uint32_t* hist_out = ws.block_hist + (size_t)blockIdx.x * 512;
-    for (int i = threadIdx.x; i < 512; i += kStreamThreads) hist_out[i] = (&queue.hist[0][0])[i];
+    // the work item's histograms are stored -- not added -- so the per-tile stage can sum them in a fixed order
+    uint32_t* hist_out = ws.block_hist + (size_t)item * 512;
+    for (int i = threadIdx.x; i < 512; i += TPB) put(&hist_out[i], (&sh->hist[0][0])[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// exact order statistics of two slots: from the gathered candidates when both brackets held, else the
-// failing slot radix-selects over the whole group (slow, exact)
+// streaming stage S4: concentrations -> rescale -> reconstruct -> clamp -> cast  (torch_backend.py:452-461,560)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ uint32_t select_whole_group(const T* __restrict__ images, const Geometry& g, const GroupState& st, int group, int slot, SelectShared<1>* sh) {
-    const GroupPixels gp = group_pixels(g, group);
-    float coef[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) coef[i] = slot < 2 ? st.vecs[i] : st.pinv[i];
-    const bool use_all = slot < 2 ? (st.use_all != 0) : true;
-    return radix_select_stream((unsigned long long)gp.count, st.rank[slot],
-                               [&](unsigned long long i, uint32_t& k) {
-                                   int64_t tile, p;
-                                   gp.locate((int64_t)i, tile, p);
-                                   float od[3];
-                                   load_od_scalar<T>(images, g.pixels, tile, p, od);
-                                   if (!od_selected(od, use_all)) return false;
-                                   if (slot < 2) {
-                                       k = angle_key(od, coef);
-                                   } else {
-                                       float c0, c1;
-                                       concentration(od, coef, c0, c1);
-                                       k = float_key(slot == 2 ? c0 : c1);
-                                   }
-                                   return true;
-                               },
-                               sh);
-}
-
-constexpr int kCandPerThread = kCap / kGroupThreads;   // 16 candidate keys per thread and slot, in registers
-
-template <typename T>
-__device__ void resolve_pair_radix(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, uint32_t (&key_out)[2], SelectShared<4>* sh) {
-    GroupState& st = ws.state[group];
-    SelectJob job[2];
-    bool ok[2];
-    uint32_t keys[2][kCandPerThread];
-    int n_mine[2];
-    const int set_of[2] = {0, 1};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int slot = first_slot + j;
-        const uint32_t ncand = st.ncand[slot];
-        const unsigned long long below = st.below[slot], want = st.rank[slot];
-        ok[j] = ncand <= (uint32_t)kCap && want >= below && want - below < ncand;
-        job[j] = SelectJob{ok[j] ? ncand : 0u, ok[j] ? want - below : 0ull, st.lo_key[slot], st.hi_key[slot]};
-        const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * kCap;
-        const uint32_t usable = ok[j] ? ncand : 0u;
-        n_mine[j] = usable > threadIdx.x ? (int)((usable - threadIdx.x + kGroupThreads - 1) / kGroupThreads) : 0;
-#pragma unroll
-        for (int i = 0; i < kCandPerThread; ++i) {   // all loads issued before the first use
-            const uint32_t idx = threadIdx.x + i * kGroupThreads;
-            keys[j][i] = idx < usable ? cand[idx] : 0xFFFFFFFFu;
-        }
-    }
-    multi_select<2, 2, kCandPerThread>(keys, n_mine, set_of, job, key_out, reinterpret_cast<SelectShared<2>*>(sh));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (ok[j]) continue;      // uniform across the workgroup
-        __syncthreads();
-        if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << (first_slot + j));
-        key_out[j] = select_whole_group<T>(images, g, st, group, first_slot + j, reinterpret_cast<SelectShared<1>*>(sh));
-    }
-}
-
-struct ResolveShared {
-    union {
-        SelectShared<4> sel;                  // radix fallback / whole-group select
-        struct {
-            uint32_t hist[2][256];
-            uint32_t list[2][kShortList];
-        } two;
-    };
-    uint32_t bin[2], count[2], result[2];
-    unsigned long long rank_in_bin[2];
-};
-
-// Exact order statistics of two slots from the candidates gathered by the streaming pass, in two levels:
-// sum the workgroups' bracket-relative histograms (fixed order), one wave per slot picks the bin holding the
-// wanted rank, the candidates of that bin (~n/256 keys) are gathered and rank-counted.  Anything unusual --
-// bracket missed or overflowed, a spilled queue, a crowded bin -- goes to the radix / whole-group paths.
-template <typename T>
-__device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, uint32_t (&key_out)[2], ResolveShared* sh) {
-    GroupState& st = ws.state[group];
-    bool ok[2];
-    uint32_t ncand[2];
-    double origin[2], scale[2];
-    unsigned long long want_in[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int slot = first_slot + j;
-        ncand[j] = st.ncand[slot];
-        const unsigned long long below = st.below[slot], want = st.rank[slot];
-        ok[j] = ncand[j] <= (uint32_t)kCap && want >= below && want - below < ncand[j] && ((st.hist_bad >> slot) & 1u) == 0;
-        want_in[j] = ok[j] ? want - below : 0ull;
-        origin[j] = st.bin_origin[slot];
-        scale[j] = st.bin_scale[slot];
-    }
-    bool simple = ok[0] && ok[1];
-    if (simple) {
-        const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
-        const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
-        if (threadIdx.x < 2) sh->count[threadIdx.x] = 0;
-        if (threadIdx.x < 512) {                       // thread t owns bin t%256 of slot t/256
-            const uint32_t* src = ws.block_hist + first * 512 + threadIdx.x;
-            uint32_t sum = 0;
-#pragma unroll 8
-            for (int64_t b = 0; b < nblk; ++b) sum += src[b * 512];
-            (&sh->two.hist[0][0])[threadIdx.x] = sum;
-        }
-        __syncthreads();
-        if (first_slot == 2) SX_STAMP(st, 5);
-        const int wave = threadIdx.x / kWave;
-        if (wave < 2) {
-            uint32_t b;
-            unsigned long long rb;
-            scan_pick(sh->two.hist[wave], want_in[wave], b, rb);
-            if (lane_id() == 0) {
-                sh->bin[wave] = b;
-                sh->rank_in_bin[wave] = rb;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t* cand = ws.cand + ((size_t)group * kSlots + first_slot + j) * kCap;
-            const uint32_t b = sh->bin[j];
-            for (uint32_t base = threadIdx.x; base < ncand[j]; base += kGroupThreads * 8) {
-                uint32_t k[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {          // eight independent loads in flight
-                    const uint32_t idx = base + u * kGroupThreads;
-                    k[u] = idx < ncand[j] ? cand[idx] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t idx = base + u * kGroupThreads;
-                    if (idx < ncand[j] && bin_of(k[u], origin[j], scale[j]) == b) {
-                        const uint32_t at = atomicAdd(&sh->count[j], 1u);
-                        if (at < (uint32_t)kShortList) sh->two.list[j][at] = k[u];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (first_slot == 2) SX_STAMP(st, 11);
-        if (sh->count[0] > (uint32_t)kShortList || sh->count[1] > (uint32_t)kShortList) {
-            simple = false;                            // crowded bin (heavy ties): radix rounds instead
-        } else {
-            rank_pick(sh->two.list[0], sh->count[0], sh->rank_in_bin[0], &sh->result[0]);
-            rank_pick(sh->two.list[1], sh->count[1], sh->rank_in_bin[1], &sh->result[1]);
-            __syncthreads();
-            if (first_slot == 2) SX_STAMP(st, 14);
-            key_out[0] = sh->result[0];
-            key_out[1] = sh->result[1];
-        }
-    }
-    if (!simple) {
-        __syncthreads();
-        resolve_pair_radix<T>(images, g, ws, group, first_slot, key_out, &sh->sel);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// per-tile kernel B: angle percentiles -> HE_source -> pseudo-inverse; concentration brackets
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kGroupThreads) void stain_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
-    const int group = blockIdx.x;
-    GroupState& st = ws.state[group];
-    const GroupPixels gp = group_pixels(g, group);
-    __shared__ union {
-        SampleShared sample;
-        ResolveShared resolve;
-    } lds;
-    SampleShared& sample_sh = lds.sample;
-    __shared__ float pinv_s[6];
-
-    uint32_t phi_key[2];
-    SX_STAMP(st, 6);
-    resolve_pair<T>(images, g, ws, group, 0, phi_key, &lds.resolve);
-    __syncthreads();
-    SX_STAMP(st, 7);
-
-    if (threadIdx.x == 0) {
-        const float phi_lo = key_float(phi_key[0]), phi_hi = key_float(phi_key[1]);
-        float he[6];
-        stain_vectors_and_pinv(st.vecs, phi_lo, phi_hi, he, pinv_s);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            st.he[i] = he[i];
-            st.pinv[i] = pinv_s[i];
-        }
-        st.phi[0] = phi_lo;
-        st.phi[1] = phi_hi;
-        st.ncand_seen[0] = st.ncand[0];
-        st.ncand_seen[1] = st.ncand[1];
-    }
-    __syncthreads();
-
-    SX_STAMP(st, 8);
-    // concentration brackets from the same strided sample (every pixel takes part: torch_backend.py:442-448)
-    const int m = (int)min((int64_t)kSample, gp.count);
-    float pinv[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pinv[i] = pinv_s[i];
-    uint32_t keys[2][kSamplePerThread];
-    const float* sample_in = ws.sample_od + (size_t)group * 3 * kSample;
-#pragma unroll
-    for (int i = 0; i < kSamplePerThread; ++i) {
-        const int j = threadIdx.x + i * kGroupThreads;
-        uint32_t ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
-        if (j < m) {
-            const float od[3] = {sample_in[j], sample_in[kSample + j], sample_in[2 * kSample + j]};
-            float c0, c1;
-            concentration(od, pinv, c0, c1);
-            ka = float_key(c0);
-            kb = float_key(c1);
-        }
-        keys[0][i] = ka;
-        keys[1][i] = kb;
-    }
-    const unsigned long long n_all = (unsigned long long)gp.count;
-    const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
-    const unsigned long long k0[2] = {k99, k99};
-    uint32_t lo[2], hi[2];
-    double b_origin[2], b_scale[2];
-    SX_STAMP(st, 9);
-    sample_brackets<2>(keys, n_all, k0, lo, hi, b_origin, b_scale, &sample_sh);
-    SX_STAMP(st, 10);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            st.rank[2 + s] = k99;
-            st.lo_key[2 + s] = lo[s];
-            st.hi_key[2 + s] = hi[s];
-            st.bin_origin[2 + s] = b_origin[s];
-            st.bin_scale[2 + s] = b_scale[s];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// per-tile kernel C: concentration percentiles -> scale factors (transform) / outputs (fit)
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kGroupThreads) void scale_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc, float* __restrict__ he_out, float* __restrict__ max_c_out) {
-    const int group = blockIdx.x;
-    GroupState& st = ws.state[group];
-    __shared__ ResolveShared sel;
-    uint32_t c_key[2];
-    SX_STAMP(st, 12);
-    resolve_pair<T>(images, g, ws, group, 2, c_key, &sel);
-    SX_STAMP(st, 13);
-    if (threadIdx.x == 0) {
-        const float m0 = key_float(c_key[0]), m1 = key_float(c_key[1]);
-        st.max_c[0] = m0;
-        st.max_c[1] = m1;
-        st.ncand_seen[2] = st.ncand[2];
-        st.ncand_seen[3] = st.ncand[3];
-        if (target_max_conc) {
-            st.scale[0] = target_max_conc[0] / m0;      // torch_backend.py:452
-            st.scale[1] = target_max_conc[1] / m1;
-        }
-        if (he_out) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) he_out[i] = st.he[i];
-            max_c_out[0] = m0;
-            max_c_out[1] = m1;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// final pass: concentrations -> rescale -> reconstruct -> clamp -> cast  (torch_backend.py:452-461,560)
-// ------------------------------------------------------------------------------------------------
-template <typename T, typename O, int V, bool kUnit>
-__global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __restrict__ images, O* __restrict__ out, Geometry g, Workspace ws, const float* __restrict__ stain_matrix) {
-    const int64_t tile = blockIdx.x / g.blocks_per_tile;
-    const int chunk_id = blockIdx.x % g.blocks_per_tile;
-    const GroupState& st = ws.state[tile];
-    const int64_t p_begin = (int64_t)chunk_id * g.chunk;
-    const int64_t p_end = min(p_begin + g.chunk, g.pixels);
+template <typename T, typename O, int V, bool kUnit, int TPB>
+__device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
+                                 const float* __restrict__ stain_matrix) {
+    const int64_t p_begin = (int64_t)chunk_id * kChunk;
+    const int64_t p_end = min(p_begin + (int64_t)kChunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
     O* dst = out + tile * 3 * g.pixels;
+    const StageRecord* rec = &ws.state[tile].rec[2];
 
     float pinv[6], sm[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        pinv[i] = st.pinv[i];
+        pinv[i] = get(&rec->coef[i]);
         sm[i] = stain_matrix[i];
     }
-    const float s0 = st.scale[0], s1 = st.scale[1];
+    const float s0 = get(&rec->scale[0]), s1 = get(&rec->scale[1]);
 
-    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
+    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
         float u[3][V];
 #pragma unroll
         for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
@@ -1252,8 +828,367 @@ __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) store_pack<O, V>(dst + c * g.pixels + p, res[c]);
+        for (int c = 0; c < 3; ++c) store_pack_stream<O, V>(dst + c * g.pixels + p, res[c]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-tile stage A ("plane"): moments -> covariance -> plane vectors; angle brackets from the sample
+// ------------------------------------------------------------------------------------------------
+__device__ void plane_stage(const Geometry& g, const Workspace& ws, int group, int allow_fallback, TileScratch* sh) {
+    GroupState& st = ws.state[group];
+    SX_STAMP(st, 0);
+    {
+        // fixed-order (deterministic) sum of the work items' partial moments: lanes fetch them in parallel, one
+        // thread per moment adds them in index order
+        const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
+        const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
+        const int rows = 12;
+        double running = 0.0;
+        for (int64_t b0 = 0; b0 < nblk; b0 += rows) {
+            const int live = (int)min((int64_t)rows, nblk - b0);
+            __syncthreads();
+            if ((int)threadIdx.x < live * kMoments) sh->stage[threadIdx.x / kMoments][threadIdx.x % kMoments] = get(&ws.partial[(first + b0) * kMoments + threadIdx.x]);
+            __syncthreads();
+            if (threadIdx.x < kMoments)
+                for (int b = 0; b < live; ++b) running += sh->stage[b][threadIdx.x];
+        }
+        if (threadIdx.x < kMoments) sh->mom[threadIdx.x] = running;
+    }
+    __syncthreads();
+    SX_STAMP(st, 1);
+    if (threadIdx.x == 0) {
+        double cov[9];
+        bool use_all;
+        unsigned long long n_sel;
+        float vecs[6];
+        plane_from_moments(sh->mom, allow_fallback != 0, cov, vecs, use_all, n_sel);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            sh->coef[i] = vecs[i];
+            put(&st.vecs[i], vecs[i]);
+        }
+        sh->flag = use_all ? 1 : 0;
+        sh->n_sel = n_sel;
+#pragma unroll
+        for (int k = 0; k < kMoments; ++k) put(&st.mom[k], sh->mom[k]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) put(&st.cov[i], cov[i]);
+        put(&st.use_all, sh->flag);
+        put(&st.n_sel, n_sel);
+        put(&st.fell_back, 0u);
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            put(&st.below[s], 0u);
+            put(&st.ncand[s], 0u);
+        }
+    }
+    __syncthreads();
+    SX_STAMP(st, 2);
+    const bool use_all = sh->flag != 0;
+    const unsigned long long n_sel = sh->n_sel;
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = sh->coef[i];
+    // angle keys of the selected sample pixels (their OD was written by S1)
+    const float* sample = ws.sample_od + (size_t)group * 3 * kSample;
+    const int m = g.sample_count;
+    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (j < m) {
+            const float od[3] = {get(&sample[j]), get(&sample[kSample + j]), get(&sample[2 * kSample + j])};
+            if (od_selected(od, use_all)) key = angle_key(od, v);
+        }
+        sh->keys[j] = key;
+    }
+    SX_STAMP(st, 3);
+    const unsigned long long k0[2] = {nearest_rank_index(1.0, n_sel), nearest_rank_index(99.0, n_sel)};   // alpha = 1 (torch_backend.py:421-422)
+    uint32_t lo[2], hi[2];
+    double origin[2], scale[2];
+    sample_brackets(sh, 2, n_sel, k0, lo, hi, origin, scale);
+    SX_STAMP(st, 4);
+    if (threadIdx.x == 0) {
+        StageRecord* rec = &st.rec[0];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) put(&rec->coef[i], v[i]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            put(&st.rank[s], k0[s]);
+            put(&rec->lo[s], lo[s]);
+            put(&rec->hi[s], hi[s]);
+            put(&rec->bin_origin[s], origin[s]);
+            put(&rec->bin_scale[s], scale[s]);
+        }
+        put(&rec->use_all, use_all ? 1 : 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact order statistics of the two slots of a stage from what the streaming stage left behind
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ uint32_t select_whole_group(const T* __restrict__ images, const Geometry& g, int group, int slot, unsigned long long rank, const float* coef, bool use_all,
+                                       TileScratch* sh) {
+    const GroupPixels gp = group_pixels(g, group);
+    return radix_select_stream((unsigned long long)gp.count, rank,
+                               [&](unsigned long long i, uint32_t& k) {
+                                   int64_t tile, p;
+                                   gp.locate((int64_t)i, tile, p);
+                                   float od[3];
+                                   load_od_scalar<T>(images, g.pixels, tile, p, od);
+                                   if (!od_selected(od, use_all)) return false;
+                                   if (slot < 2) {
+                                       k = angle_key(od, coef);
+                                   } else {
+                                       float c0, c1;
+                                       concentration(od, coef, c0, c1);
+                                       k = float_key(slot == 2 ? c0 : c1);
+                                   }
+                                   return true;
+                               },
+                               sh);
+}
+
+// Sum the work items' bracket-relative histograms (fixed order), one wave per slot picks the bin holding the
+// wanted rank, the candidates of that bin (~n/256 keys) are gathered and rank-counted.  Anything unusual --
+// bracket missed or overflowed, a crowded bin -- goes to the radix paths (over the candidates, or recomputing
+// every key of the group from the pixels).
+template <typename T>
+__device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, const float* coef, bool use_all,
+                             uint32_t (&key_out)[2], TileScratch* sh) {
+    GroupState& st = ws.state[group];
+    const StageRecord* rec = &st.rec[first_slot ? 1 : 0];
+    bool ok[2];
+    uint32_t ncand[2];
+    double origin[2], scale[2];
+    unsigned long long want_in[2], want_all[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int slot = first_slot + j;
+        ncand[j] = get(&st.ncand[slot]);
+        const unsigned long long below = get(&st.below[slot]);
+        want_all[j] = get(&st.rank[slot]);
+        ok[j] = ncand[j] <= (uint32_t)kCap && want_all[j] >= below && want_all[j] - below < ncand[j];
+        want_in[j] = ok[j] ? want_all[j] - below : 0ull;
+        origin[j] = get(&rec->bin_origin[j]);
+        scale[j] = get(&rec->bin_scale[j]);
+    }
+    __syncthreads();
+    const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
+    const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
+    if (threadIdx.x < 2) sh->count[threadIdx.x] = 0;
+    for (int t = threadIdx.x; t < 512; t += blockDim.x) {     // thread owns bin t%256 of slot t/256
+        const uint32_t* src = ws.block_hist + first * 512 + t;
+        uint32_t sum = 0;
+#pragma unroll 8
+        for (int64_t b = 0; b < nblk; ++b) sum += get(&src[b * 512]);
+        (&sh->hist[0][0])[t] = sum;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (wave == j && ok[j]) {
+            uint32_t b;
+            unsigned long long rb;
+            scan_pick(sh->hist[j], want_in[j], b, rb);
+            if (lane_id() == 0) {
+                sh->bin[j] = b;
+                sh->rank_in_bin[j] = rb;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (!ok[j]) continue;
+        const uint32_t* cand = ws.cand + ((size_t)group * kSlots + first_slot + j) * kCap;
+        const uint32_t b = sh->bin[j];
+        for (uint32_t base = threadIdx.x; base < ncand[j]; base += blockDim.x * 8) {
+            uint32_t k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {          // eight independent loads in flight
+                const uint32_t idx = base + u * blockDim.x;
+                k[u] = idx < ncand[j] ? get(&cand[idx]) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t idx = base + u * blockDim.x;
+                if (idx < ncand[j] && bin_of(k[u], origin[j], scale[j]) == b) {
+                    const uint32_t at = atomicAdd(&sh->count[j], 1u);
+                    if (at < (uint32_t)kShortList) sh->list[j][at] = k[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int slot = first_slot + j;
+        if (ok[j] && sh->count[j] <= (uint32_t)kShortList) {
+            rank_pick(sh->list[j], sh->count[j], sh->rank_in_bin[j], &sh->result[j]);
+            __syncthreads();
+            key_out[j] = sh->result[j];
+        } else if (ok[j]) {      // crowded bin: radix rounds over the candidates
+            const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * kCap;
+            if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
+            key_out[j] = radix_select_stream((unsigned long long)ncand[j], want_in[j], [cand](unsigned long long i, uint32_t& k) { k = get(&cand[i]); return true; }, sh);
+        } else {                 // the bracket did not hold: recompute every key of the group
+            if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << slot);
+            key_out[j] = select_whole_group<T>(images, g, group, slot, want_all[j], coef, use_all, sh);
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-tile stage B ("stain"): angle percentiles -> HE_source -> pseudo-inverse; concentration brackets
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void stain_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, TileScratch* sh) {
+    GroupState& st = ws.state[group];
+    const GroupPixels gp = group_pixels(g, group);
+    SX_STAMP(st, 6);
+    float vecs[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vecs[i] = get(&st.rec[0].coef[i]);
+    const bool use_all = get(&st.rec[0].use_all) != 0;
+    uint32_t phi_key[2];
+    resolve_pair<T>(images, g, ws, group, 0, vecs, use_all, phi_key, sh);
+    SX_STAMP(st, 7);
+    if (threadIdx.x == 0) {
+        const float phi_lo = angle_from_key(phi_key[0]), phi_hi = angle_from_key(phi_key[1]);
+        float he[6], pinv[6];
+        stain_vectors_and_pinv(vecs, phi_lo, phi_hi, he, pinv);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            put(&st.he[i], he[i]);
+            put(&st.pinv[i], pinv[i]);
+            sh->coef[i] = pinv[i];
+        }
+        put(&st.phi[0], phi_lo);
+        put(&st.phi[1], phi_hi);
+        put(&st.ncand_seen[0], get(&st.ncand[0]));
+        put(&st.ncand_seen[1], get(&st.ncand[1]));
+    }
+    __syncthreads();
+    SX_STAMP(st, 8);
+    // concentration brackets from the same strided sample (every pixel takes part: torch_backend.py:442-448),
+    // one key set at a time
+    float pinv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pinv[i] = sh->coef[i];
+    const float* sample = ws.sample_od + (size_t)group * 3 * kSample;
+    const int m = g.sample_count;
+    const unsigned long long n_all = (unsigned long long)gp.count;
+    const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
+    uint32_t lo[2], hi[2];
+    double origin[2], scale[2];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (j < m) {
+                const float od[3] = {get(&sample[j]), get(&sample[kSample + j]), get(&sample[2 * kSample + j])};
+                float c0, c1;
+                concentration(od, pinv, c0, c1);
+                key = float_key(which == 0 ? c0 : c1);
+            }
+            sh->keys[j] = key;
+        }
+        sample_brackets(sh, 1, n_all, &k99, &lo[which], &hi[which], &origin[which], &scale[which]);
+    }
+    SX_STAMP(st, 10);
+    if (threadIdx.x == 0) {
+        StageRecord* rec = &st.rec[1];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) put(&rec->coef[i], pinv[i]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            put(&st.rank[2 + s], k99);
+            put(&rec->lo[s], lo[s]);
+            put(&rec->hi[s], hi[s]);
+            put(&rec->bin_origin[s], origin[s]);
+            put(&rec->bin_scale[s], scale[s]);
+        }
+        put(&rec->use_all, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-tile stage C ("scale"): concentration percentiles -> scale factors (transform) / outputs (fit)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void scale_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, const float* __restrict__ target_max_conc, float* __restrict__ he_out,
+                            float* __restrict__ max_c_out, TileScratch* sh) {
+    GroupState& st = ws.state[group];
+    SX_STAMP(st, 12);
+    float pinv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pinv[i] = get(&st.rec[1].coef[i]);
+    uint32_t c_key[2];
+    resolve_pair<T>(images, g, ws, group, 2, pinv, true, c_key, sh);
+    SX_STAMP(st, 13);
+    if (threadIdx.x == 0) {
+        const float m0 = key_float(c_key[0]), m1 = key_float(c_key[1]);
+        put(&st.max_c[0], m0);
+        put(&st.max_c[1], m1);
+        put(&st.ncand_seen[2], get(&st.ncand[2]));
+        put(&st.ncand_seen[3], get(&st.ncand[3]));
+        StageRecord* rec = &st.rec[2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) put(&rec->coef[i], pinv[i]);
+        if (target_max_conc) {
+            put(&rec->scale[0], target_max_conc[0] / m0);      // torch_backend.py:452
+            put(&rec->scale[1], target_max_conc[1] / m1);
+        }
+        if (he_out) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) he_out[i] = get(&st.he[i]);
+            max_c_out[0] = m0;
+            max_c_out[1] = m1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels, one launch per stage (pooled fit; also the transform path when STAINX_HIP_PERSISTENT=0)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
+    __shared__ StatsScratch<kStreamThreads> sh;
+    stats_item<T, V, kStreamThreads>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh);
+}
+
+template <typename T, int V, bool kConc>
+__global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
+    __shared__ BracketScratch<kStreamThreads> sh;
+    bracket_item<T, V, kConc, kStreamThreads>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh);
+}
+
+template <typename T, typename O, int V, bool kUnit>
+__global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __restrict__ images, O* __restrict__ out, Geometry g, Workspace ws, const float* __restrict__ stain_matrix) {
+    reconstruct_item<T, O, V, kUnit, kStreamThreads>(images, out, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, stain_matrix);
+}
+
+constexpr int kGroupThreads = 1024;    // per-tile stages as their own launch
+
+__global__ __launch_bounds__(kGroupThreads) void plane_kernel(Geometry g, Workspace ws, int allow_fallback) {
+    __shared__ TileScratch sh;
+    plane_stage(g, ws, blockIdx.x, allow_fallback, &sh);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGroupThreads) void stain_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
+    __shared__ TileScratch sh;
+    stain_stage<T>(images, g, ws, blockIdx.x, &sh);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGroupThreads) void scale_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc, float* __restrict__ he_out, float* __restrict__ max_c_out) {
+    __shared__ TileScratch sh;
+    scale_stage<T>(images, g, ws, blockIdx.x, target_max_conc, he_out, max_c_out, &sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1299,7 +1234,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(kStreamThreads) void dfit_histogram_kernel(const T* __restrict__ images, Geometry g, const DFitState* __restrict__ st, int stage, unsigned long long* __restrict__ hist) {
     const int64_t tile = blockIdx.x / g.blocks_per_tile;
     const int chunk_id = blockIdx.x % g.blocks_per_tile;
-    const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
+    const int64_t p_begin = (int64_t)chunk_id * kChunk, p_end = min(p_begin + (int64_t)kChunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
     __shared__ uint32_t local[2][256];
     for (int i = threadIdx.x; i < 512; i += kStreamThreads) (&local[0][0])[i] = 0;
@@ -1341,10 +1276,8 @@ __global__ __launch_bounds__(kStreamThreads) void dfit_histogram_kernel(const T*
 }
 
 __global__ __launch_bounds__(128) void dfit_advance_kernel(DFitState* __restrict__ st, int stage, const unsigned long long* __restrict__ hist) {
-    __shared__ uint32_t bins[2][256];
-    __shared__ unsigned long long carry[2][256];
     const int s0 = stage * 2;
-    // histograms can exceed 2^32 per bin in principle: scan in 64 bit with one thread per slot
+    // bins can exceed 2^32 in principle: scan in 64 bit with one thread per slot
     if (threadIdx.x < 2) {
         const int j = threadIdx.x;
         unsigned long long r = st->rank[s0 + j], cum = 0;
@@ -1359,14 +1292,12 @@ __global__ __launch_bounds__(128) void dfit_advance_kernel(DFitState* __restrict
         st->mask[s0 + j] |= 0xFFu << shift;
         st->rank[s0 + j] = r - cum;
     }
-    (void)bins;
-    (void)carry;
     __syncthreads();
     if (threadIdx.x != 0) return;
     st->round[stage] += 1;
     if (st->round[stage] < 4) return;
     if (stage == 0) {
-        const float phi_lo = key_float(st->prefix[0]), phi_hi = key_float(st->prefix[1]);
+        const float phi_lo = angle_from_key(st->prefix[0]), phi_hi = angle_from_key(st->prefix[1]);
         st->phi[0] = phi_lo;
         st->phi[1] = phi_hi;
         stain_vectors_and_pinv(st->vecs, phi_lo, phi_hi, st->he, st->pinv);
@@ -1406,11 +1337,19 @@ __global__ void export_params_kernel(const GroupState* __restrict__ state, int64
 // ------------------------------------------------------------------------------------------------
 static bool aligned_for(const void* p, size_t bytes) { return (reinterpret_cast<uintptr_t>(p) % bytes) == 0; }
 
+static void set_sampling(Geometry& g) {
+    const int64_t count = g.pooled ? g.n_tiles * g.pixels : g.pixels;
+    int64_t stride = 1;                                   // smallest power of two with ceil(count/stride) <= kSample
+    while ((count + stride - 1) / stride > kSample) stride *= 2;
+    g.sample_stride = (int)stride;
+    g.sample_count = (int)std::min<int64_t>(kSample, (count + stride - 1) / stride);
+}
+
 template <typename T, int V>
 static int run_estimate(const T* images, const Geometry& g, const Workspace& ws, int n_groups, int allow_fallback, const float* tmc, float* he_out, float* max_c_out, hipStream_t stream) {
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
-    hipLaunchKernelGGL((stats_kernel<T, V>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws.partial);
-    hipLaunchKernelGGL((plane_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws, allow_fallback);
+    hipLaunchKernelGGL((stats_kernel<T, V>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL(plane_kernel, dim3(n_groups), dim3(kGroupThreads), 0, stream, g, ws, allow_fallback);
     hipLaunchKernelGGL((bracket_kernel<T, V, false>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((stain_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((bracket_kernel<T, V, true>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
@@ -1420,13 +1359,13 @@ static int run_estimate(const T* images, const Geometry& g, const Workspace& ws,
 
 template <typename T, typename O, int V>
 static int run_transform(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
+    const unsigned items = (unsigned)(g.n_tiles * g.blocks_per_tile);
     int rc = run_estimate<T, V>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
     if (rc != SX_OK) return rc;
-    const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     if (unit)
-        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, true>), dim3(grid), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
+        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, true>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
     else
-        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, false>), dim3(grid), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
+        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, false>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
     return check_launch("macenko reconstruct");
 }
 
@@ -1436,7 +1375,8 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     const bool u8_unit = unit && sizeof(T) == 1;
     const size_t out_elem = u8_unit ? sizeof(float) : sizeof(T);
     const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4) && aligned_for(out, out_elem * 4);
-    g.chunk = kStreamThreads * (vec ? 4 : 1) * kIters * (vec ? 1 : 4);   // same pixels per workgroup on both paths
+    g.vec = vec ? 1 : 0;
+    set_sampling(g);
     const T* in = static_cast<const T*>(images);
     if constexpr (sizeof(T) == 1) {
         if (u8_unit) {
@@ -1452,25 +1392,26 @@ template <typename T>
 static int fit_typed(const void* images, const Geometry& g0, const Workspace& ws, float* he_out, float* max_c_out, hipStream_t stream) {
     Geometry g = g0;
     const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4);
-    g.chunk = kStreamThreads * (vec ? 4 : 1) * kIters * (vec ? 1 : 4);
+    g.vec = vec ? 1 : 0;
+    set_sampling(g);
     const T* in = static_cast<const T*>(images);
     return vec ? run_estimate<T, 4>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream)
                : run_estimate<T, 1>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream);
 }
-
 
 // ---- distributed pooled fit: staged entry points (host does the all-reduces in between) -----------
 template <typename T>
 static int dfit_moments_typed(const void* images, const Geometry& g0, const Workspace& ws, double* moments, hipStream_t stream) {
     Geometry g = g0;
     const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4);
-    g.chunk = kStreamThreads * 4 * kIters;
+    g.vec = vec ? 1 : 0;
+    set_sampling(g);
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
     if (vec)
-        hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws.partial);
+        hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
     else
-        hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws.partial);
+        hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
     hipLaunchKernelGGL(dfit_reduce_partials_kernel, dim3(1), dim3(64), 0, stream, ws.partial, (int64_t)grid, moments);
     return check_launch("macenko dfit moments");
 }
@@ -1479,7 +1420,7 @@ template <typename T>
 static int dfit_histogram_typed(const void* images, const Geometry& g0, const DFitState* st, int stage, unsigned long long* hist, hipStream_t stream) {
     Geometry g = g0;
     const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4);
-    g.chunk = kStreamThreads * 4 * kIters;
+    g.vec = vec ? 1 : 0;
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
     if (hipMemsetAsync(hist, 0, 512 * sizeof(unsigned long long), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
@@ -1514,7 +1455,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -1532,7 +1473,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -1559,7 +1500,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -1581,7 +1522,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
