@@ -116,24 +116,30 @@ template <typename T>
 __global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, const unsigned long long* __restrict__ counts, const float* __restrict__ ref_hist, double num_pixels) {
     const int c = blockIdx.x, t = threadIdx.x;
     __shared__ float src_cdf[kBins], ref_cdf[kBins];
-    __shared__ float ref_total_s;
-    if (t == 0) {
-        // source: counts / float(num_pixels + 1e-8), running sum in double rounded per entry (:235-236)
-        const float denom = (float)(num_pixels + 1e-8);
+    __shared__ float src_term[kBins], ref_term[kBins];
+    __shared__ float ref_denom_s;
+    // the divisions run one per thread; only the two running sums are sequential (that order is torch.cumsum's)
+    if (t == 64) {
+        // reference: h / (sum(h) + 1e-8) (:222-223)
+        double tot = 0.0;
+        for (int b = 0; b < kBins; ++b) tot += (double)ref_hist[c * kBins + b];
+        ref_denom_s = (float)tot + 1e-8f;
+    }
+    // source: counts / float(num_pixels + 1e-8) (:235)
+    src_term[t] = (float)counts[c * kBins + t] / (float)(num_pixels + 1e-8);
+    __syncthreads();
+    ref_term[t] = ref_hist[c * kBins + t] / ref_denom_s;
+    __syncthreads();
+    if (t == 0) {          // running sum in double rounded per entry (:236)
         double run = 0.0;
         for (int b = 0; b < kBins; ++b) {
-            run += (double)((float)counts[c * kBins + b] / denom);
+            run += (double)src_term[b];
             src_cdf[b] = (float)run;
         }
     } else if (t == 64) {
-        // reference: h / (sum(h) + 1e-8), then the same prefix sum (:222-223)
-        double tot = 0.0;
-        for (int b = 0; b < kBins; ++b) tot += (double)ref_hist[c * kBins + b];
-        const float denom = (float)tot + 1e-8f;
-        ref_total_s = denom;
         double run = 0.0;
         for (int b = 0; b < kBins; ++b) {
-            run += (double)(ref_hist[c * kBins + b] / denom);
+            run += (double)ref_term[b];
             ref_cdf[b] = (float)run;
         }
     }

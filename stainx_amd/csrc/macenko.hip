@@ -191,15 +191,25 @@ __device__ __forceinline__ void load_od_scalar(const T* __restrict__ images, int
 // ------------------------------------------------------------------------------------------------
 // small numerics of the per-tile stages
 // ------------------------------------------------------------------------------------------------
-// One Jacobi rotation in the (p,q) plane of a symmetric 3x3 kept in scalars (r is the third index).
+// One Jacobi rotation in the (p,q) plane of a symmetric 3x3 kept in scalars (r is the third index).  The angle is
+// worked out in fp32 (hardware rcp / sqrt / rsq: a chain of software fp64 divisions and roots costs ~1 us per
+// rotation on one lane), then (c,s) is renormalised in fp64 so the transform stays orthogonal to 1e-14; the update
+// is the full similarity transform, exact for any orthonormal (c,s), so an angle that is only fp32-accurate just
+// leaves a 1e-7-times smaller off-diagonal for the next sweep.
 #define SX_JACOBI_ROTATE(app, aqq, apq, arp, arq, v0p, v0q, v1p, v1q, v2p, v2q)            \
     if ((apq) != 0.0) {                                                                      \
-        const double theta = ((aqq) - (app)) / (2.0 * (apq));                                \
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
-        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;                                \
-        (app) -= t * (apq);                                                                  \
-        (aqq) += t * (apq);                                                                  \
-        (apq) = 0.0;                                                                         \
+        const float theta = (float)((aqq) - (app)) / (float)(2.0 * (apq));                   \
+        const float tf = copysignf(1.0f, theta) / (fabsf(theta) + sqrtf(fmaf(theta, theta, 1.0f))); \
+        const float cf = rsqrtf(fmaf(tf, tf, 1.0f));                                         \
+        double c = (double)cf, sn = (double)(tf * cf);                                       \
+        const double fix = 1.5 - 0.5 * (c * c + sn * sn);                                    \
+        c *= fix;                                                                            \
+        sn *= fix;                                                                           \
+        const double cc = c * c, ss = sn * sn, cs = c * sn;                                  \
+        const double pp = (app), qq = (aqq), pq = (apq);                                     \
+        (app) = cc * pp - 2.0 * cs * pq + ss * qq;                                           \
+        (aqq) = ss * pp + 2.0 * cs * pq + cc * qq;                                           \
+        (apq) = (cc - ss) * pq + cs * (pp - qq);                                             \
         const double rp = (arp), rq = (arq);                                                 \
         (arp) = c * rp - sn * rq;                                                            \
         (arq) = sn * rp + c * rq;                                                            \
@@ -384,32 +394,16 @@ __device__ __forceinline__ double bin_scale_for(uint32_t lo, uint32_t hi) {
     return (span > 0.0 && span < 1e300) ? 256.0 / span : 0.0;
 }
 
-// Exact r-th smallest (0-based, ties by index) of a short LDS list by rank counting: each wave takes every
-// n_waves-th element, its lanes split the comparisons and add their counts up.  Whole workgroup calls it.
-__device__ __forceinline__ void rank_pick(const uint32_t* list, uint32_t n, unsigned long long r, uint32_t* out) {
-    const uint32_t wave = threadIdx.x / kWave, n_waves = blockDim.x / kWave, lane = lane_id();
-    for (uint32_t i = wave; i < n; i += n_waves) {
-        const uint32_t k = list[i];
-        uint32_t c = 0;
-        for (uint32_t t = lane; t < n; t += kWave) {
-            const uint32_t x = list[t];
-            c += (x < k || (x == k && t < i)) ? 1u : 0u;
-        }
-        c = wave_sum_u32(c);
-        if (lane == 0 && c == r) *out = k;
-    }
-}
-
 // LDS scratch of a per-tile stage (one workgroup).
 struct TileScratch {
-    uint32_t keys[kSample];               // keys of the sample (one key set at a time)
+    uint32_t keys[2][kSample];            // keys of the sample: one set for the angle, two for the concentrations
     uint32_t hist[2][256];
     uint32_t list[4][kShortList];
     double mom[kMoments];
-    double stage[12][kMoments];
+    double stage[32][kMoments];
     unsigned long long rank_in_bin[4], radix_rank, n_sel;
     uint32_t bin[4], count[4], result[4];
-    uint32_t range_lo, range_hi, radix_digit;
+    uint32_t range_lo[2], range_hi[2], radix_digit;
     int valid;
     float coef[6];
     int flag;
@@ -447,51 +441,61 @@ __device__ uint32_t radix_select_stream(unsigned long long count, unsigned long 
     return prefix;
 }
 
-// Brackets for up to two wanted ranks (k0[0..n_ranks)) of n_total keys from the kSample sample keys in
-// sh->keys (invalid entries are 0xFFFFFFFF).  Two levels: one 256-bin value-linear histogram of the sample over
+// Two brackets from the sample keys in sh->keys (invalid entries are 0xFFFFFFFF).  n_sets == 1: both brackets
+// (wanted ranks k0[0], k0[1]) are taken in key set 0 (the two angle percentiles); n_sets == 2: bracket s is taken in
+// key set s (the two concentrations).  Two levels: one 256-bin value-linear histogram per key set over its
 // [min,max], one wave per wanted sample rank picks its bin, the keys of that bin are gathered and the exact
-// element found by rank counting (a crowded bin falls back to radix rounds).  Outputs per wanted rank: the
-// bracket keys and the (origin, scale) of the bracket-relative bins used for the candidates.
-__device__ void sample_brackets(TileScratch* sh, int n_ranks, unsigned long long n_total, const unsigned long long* k0, uint32_t* lo, uint32_t* hi,
-                                double* bin_origin, double* bin_scale) {
+// element found by rank counting (a crowded bin falls back to radix rounds).  Outputs per bracket: the bracket
+// keys and the (origin, scale) of the bracket-relative bins used for the candidates.
+__device__ void sample_brackets(TileScratch* sh, int n_sets, unsigned long long n_total, const unsigned long long (&k0)[2], uint32_t (&lo)[2], uint32_t (&hi)[2],
+                                double (&bin_origin)[2], double (&bin_scale)[2]) {
     __syncthreads();
-    if (threadIdx.x == 0) {
-        sh->range_lo = 0xFFFFFFFFu;
-        sh->range_hi = 0u;
-        sh->valid = 0;
+    if (threadIdx.x < 2) {
+        sh->range_lo[threadIdx.x] = 0xFFFFFFFFu;
+        sh->range_hi[threadIdx.x] = 0u;
     }
+    if (threadIdx.x == 0) sh->valid = 0;
     if (threadIdx.x < 4) sh->count[threadIdx.x] = 0;
-    for (int t = threadIdx.x; t < 256; t += blockDim.x) sh->hist[0][t] = 0;
+    for (int t = threadIdx.x; t < 512; t += blockDim.x) (&sh->hist[0][0])[t] = 0;
     __syncthreads();
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u, valid = 0;
-    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
-        const uint32_t k = sh->keys[j];
-        if (k != 0xFFFFFFFFu) {
-            mn = min(mn, k);
-            mx = max(mx, k);
-            ++valid;
+    uint32_t valid = 0;
+    for (int set = 0; set < n_sets; ++set) {
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+            const uint32_t k = sh->keys[set][j];
+            if (k != 0xFFFFFFFFu) {
+                mn = min(mn, k);
+                mx = max(mx, k);
+                if (set == 0) ++valid;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_down(mn, off, kWave));
+            mx = max(mx, (uint32_t)__shfl_down(mx, off, kWave));
+        }
+        if (lane_id() == 0) {
+            atomicMin(&sh->range_lo[set], mn);
+            atomicMax(&sh->range_hi[set], mx);
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = min(mn, (uint32_t)__shfl_down(mn, off, kWave));
-        mx = max(mx, (uint32_t)__shfl_down(mx, off, kWave));
-    }
     valid = wave_sum_u32(valid);
-    if (lane_id() == 0) {
-        atomicMin(&sh->range_lo, mn);
-        atomicMax(&sh->range_hi, mx);
-        if (valid) atomicAdd(&sh->valid, (int)valid);
-    }
+    if (lane_id() == 0 && valid) atomicAdd(&sh->valid, (int)valid);
     __syncthreads();
-    const int m_valid = sh->valid;
-    const uint32_t set_lo = sh->range_lo, set_hi = sh->range_hi;
-    const double origin = bin_origin_for(set_lo), scale = bin_scale_for(set_lo, set_hi);
-    bool want[4] = {false, false, false, false};
-    unsigned long long rank[4] = {0, 0, 0, 0};
+    const int m_valid = sh->valid;     // both concentration sets hold every sample pixel, so set 0's count serves both
+    uint32_t set_lo[2], set_hi[2];
+    double origin[2], scale[2];
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+        set_lo[set] = sh->range_lo[set < n_sets ? set : 0];
+        set_hi[set] = sh->range_hi[set < n_sets ? set : 0];
+        origin[set] = bin_origin_for(set_lo[set]);
+        scale[set] = bin_scale_for(set_lo[set], set_hi[set]);
+    }
+    bool want[4];
+    unsigned long long rank[4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        if (s >= n_ranks) continue;
         long long lo_r, hi_r;
         bracket_ranks(m_valid, n_total, k0[s], lo_r, hi_r);
         want[2 * s] = m_valid > 0 && lo_r >= 0;
@@ -499,10 +503,11 @@ __device__ void sample_brackets(TileScratch* sh, int n_ranks, unsigned long long
         rank[2 * s] = (unsigned long long)(lo_r < 0 ? 0 : lo_r);
         rank[2 * s + 1] = (unsigned long long)(hi_r < 0 ? 0 : hi_r);
     }
-    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
-        const uint32_t k = sh->keys[j];
-        if (k != 0xFFFFFFFFu) atomicAdd(&sh->hist[0][bin_of(k, origin, scale)], 1u);
-    }
+    for (int set = 0; set < n_sets; ++set)
+        for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+            const uint32_t k = sh->keys[set][j];
+            if (k != 0xFFFFFFFFu) atomicAdd(&sh->hist[set][bin_of(k, origin[set], scale[set])], 1u);
+        }
     __syncthreads();
     const int wave = threadIdx.x / kWave;
 #pragma unroll
@@ -510,7 +515,7 @@ __device__ void sample_brackets(TileScratch* sh, int n_ranks, unsigned long long
         if (wave == q && want[q]) {
             uint32_t b;
             unsigned long long rb;
-            scan_pick(sh->hist[0], rank[q], b, rb);
+            scan_pick(sh->hist[n_sets == 2 ? (q >> 1) : 0], rank[q], b, rb);
             if (lane_id() == 0) {
                 sh->bin[q] = b;
                 sh->rank_in_bin[q] = rb;
@@ -518,40 +523,66 @@ __device__ void sample_brackets(TileScratch* sh, int n_ranks, unsigned long long
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
-        const uint32_t k = sh->keys[j];
-        if (k == 0xFFFFFFFFu) continue;
-        const uint32_t b = bin_of(k, origin, scale);
+    for (int set = 0; set < n_sets; ++set)
+        for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+            const uint32_t k = sh->keys[set][j];
+            if (k == 0xFFFFFFFFu) continue;
+            const uint32_t b = bin_of(k, origin[set], scale[set]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (want[q] && b == sh->bin[q]) {
-                const uint32_t at = atomicAdd(&sh->count[q], 1u);
-                if (at < (uint32_t)kShortList) sh->list[q][at] = k;
+            for (int q = 0; q < 4; ++q) {
+                const int q_set = n_sets == 2 ? (q >> 1) : 0;
+                if (q_set == set && want[q] && b == sh->bin[q]) {
+                    const uint32_t at = atomicAdd(&sh->count[q], 1u);
+                    if (at < (uint32_t)kShortList) sh->list[q][at] = k;
+                }
             }
         }
-    }
     __syncthreads();
     uint32_t res[4] = {0, 0, 0, 0};
+    bool crowded = false;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (!want[q]) continue;
-        if (sh->count[q] <= (uint32_t)kShortList) {
-            rank_pick(sh->list[q], sh->count[q], sh->rank_in_bin[q], &sh->result[q]);
-            __syncthreads();
-            res[q] = sh->result[q];
-        } else {    // crowded bin (uniform decision: the count lives in LDS)
-            const uint32_t* keys = sh->keys;
+    for (int q = 0; q < 4; ++q)
+        if (want[q] && sh->count[q] > (uint32_t)kShortList) crowded = true;
+    if (!crowded) {
+        // the four short lists are ranked side by side: a quarter of the waves each
+        const int n_waves = blockDim.x / kWave, per = n_waves >= 4 ? n_waves / 4 : 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!want[q]) continue;
+            const int first = n_waves >= 4 ? q * per : 0;
+            if (wave >= first && wave < first + per) {
+                const uint32_t n = sh->count[q], lane = lane_id();
+                for (uint32_t i = (uint32_t)(wave - first); i < n; i += (uint32_t)per) {
+                    const uint32_t k = sh->list[q][i];
+                    uint32_t c = 0;
+                    for (uint32_t t = lane; t < n; t += kWave) {
+                        const uint32_t x = sh->list[q][t];
+                        c += (x < k || (x == k && t < i)) ? 1u : 0u;
+                    }
+                    c = wave_sum_u32(c);
+                    if (lane == 0 && c == sh->rank_in_bin[q]) sh->result[q] = k;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) res[q] = sh->result[q];
+    } else {    // a crowded bin (uniform decision: the counts live in LDS): radix rounds over the sample
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!want[q]) continue;
+            const uint32_t* keys = sh->keys[n_sets == 2 ? (q >> 1) : 0];
             res[q] = radix_select_stream((unsigned long long)kSample, rank[q], [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return k != 0xFFFFFFFFu; }, sh);
         }
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        if (s >= n_ranks) continue;
+        const int set = n_sets == 2 ? s : 0;
         lo[s] = want[2 * s] ? res[2 * s] : 0u;
         hi[s] = want[2 * s + 1] ? res[2 * s + 1] : 0xFFFFFFFFu;
         // candidate bins span the bracket; an open side is bounded by the sample's extreme (the few keys beyond it
         // fall into the end bin)
-        const uint32_t range_lo = want[2 * s] ? res[2 * s] : set_lo, range_hi = want[2 * s + 1] ? res[2 * s + 1] : set_hi;
+        const uint32_t range_lo = want[2 * s] ? res[2 * s] : set_lo[set], range_hi = want[2 * s + 1] ? res[2 * s + 1] : set_hi[set];
         bin_origin[s] = bin_origin_for(range_lo);
         bin_scale[s] = m_valid > 0 ? bin_scale_for(range_lo, range_hi) : 0.0;
     }
@@ -843,7 +874,7 @@ __device__ void plane_stage(const Geometry& g, const Workspace& ws, int group, i
         // thread per moment adds them in index order
         const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
         const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
-        const int rows = 12;
+        const int rows = 32;
         double running = 0.0;
         for (int64_t b0 = 0; b0 < nblk; b0 += rows) {
             const int live = (int)min((int64_t)rows, nblk - b0);
@@ -899,13 +930,13 @@ __device__ void plane_stage(const Geometry& g, const Workspace& ws, int group, i
             const float od[3] = {get(&sample[j]), get(&sample[kSample + j]), get(&sample[2 * kSample + j])};
             if (od_selected(od, use_all)) key = angle_key(od, v);
         }
-        sh->keys[j] = key;
+        sh->keys[0][j] = key;
     }
     SX_STAMP(st, 3);
     const unsigned long long k0[2] = {nearest_rank_index(1.0, n_sel), nearest_rank_index(99.0, n_sel)};   // alpha = 1 (torch_backend.py:421-422)
     uint32_t lo[2], hi[2];
     double origin[2], scale[2];
-    sample_brackets(sh, 2, n_sel, k0, lo, hi, origin, scale);
+    sample_brackets(sh, 1, n_sel, k0, lo, hi, origin, scale);
     SX_STAMP(st, 4);
     if (threadIdx.x == 0) {
         StageRecord* rec = &st.rec[0];
@@ -1022,13 +1053,33 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
         }
     }
     __syncthreads();
+    {   // rank counting of the two short lists, half the waves each
+        const int n_waves = blockDim.x / kWave, half = n_waves >= 2 ? n_waves / 2 : 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!(ok[j] && sh->count[j] <= (uint32_t)kShortList)) continue;
+            const int first = n_waves >= 2 ? j * half : 0;
+            if (wave >= first && wave < first + half) {
+                const uint32_t n = sh->count[j], lane = lane_id();
+                for (uint32_t i = (uint32_t)(wave - first); i < n; i += (uint32_t)half) {
+                    const uint32_t k = sh->list[j][i];
+                    uint32_t c = 0;
+                    for (uint32_t t = lane; t < n; t += kWave) {
+                        const uint32_t x = sh->list[j][t];
+                        c += (x < k || (x == k && t < i)) ? 1u : 0u;
+                    }
+                    c = wave_sum_u32(c);
+                    if (lane == 0 && c == sh->rank_in_bin[j]) sh->result[j] = k;
+                }
+            }
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int slot = first_slot + j;
         if (ok[j] && sh->count[j] <= (uint32_t)kShortList) {
-            rank_pick(sh->list[j], sh->count[j], sh->rank_in_bin[j], &sh->result[j]);
-            __syncthreads();
-            key_out[j] = sh->result[j];
+            key_out[j] = sh->result[j];        // ranked above, both lists side by side
         } else if (ok[j]) {      // crowded bin: radix rounds over the candidates
             const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * kCap;
             if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
@@ -1084,21 +1135,21 @@ __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, con
     const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
     uint32_t lo[2], hi[2];
     double origin[2], scale[2];
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        __syncthreads();
-        for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
-            uint32_t key = 0xFFFFFFFFu;
-            if (j < m) {
-                const float od[3] = {get(&sample[j]), get(&sample[kSample + j]), get(&sample[2 * kSample + j])};
-                float c0, c1;
-                concentration(od, pinv, c0, c1);
-                key = float_key(which == 0 ? c0 : c1);
-            }
-            sh->keys[j] = key;
+    __syncthreads();
+    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+        uint32_t ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
+        if (j < m) {
+            const float od[3] = {get(&sample[j]), get(&sample[kSample + j]), get(&sample[2 * kSample + j])};
+            float c0, c1;
+            concentration(od, pinv, c0, c1);
+            ka = float_key(c0);
+            kb = float_key(c1);
         }
-        sample_brackets(sh, 1, n_all, &k99, &lo[which], &hi[which], &origin[which], &scale[which]);
+        sh->keys[0][j] = ka;
+        sh->keys[1][j] = kb;
     }
+    const unsigned long long k0[2] = {k99, k99};
+    sample_brackets(sh, 2, n_all, k0, lo, hi, origin, scale);
     SX_STAMP(st, 10);
     if (threadIdx.x == 0) {
         StageRecord* rec = &st.rec[1];

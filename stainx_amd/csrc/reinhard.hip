@@ -22,7 +22,8 @@ struct alignas(256) State {
     unsigned int arrivals;
 };
 
-// pow through v_log_f32 / v_exp_f32; x > 0
+// Divisions by the colour-space constants are multiplications by their reciprocals (<= 1 ulp from the reference's
+// divisions, far inside the 1e-4 tolerance); pow goes through v_log_f32 / v_exp_f32; x > 0
 __device__ __forceinline__ float fast_pow(float x, float e) { return exp2f(e * __log2f(x)); }
 
 // Centre of the LAB accumulators: keeps sum-of-squares small (values are shifted, not rescaled).
@@ -32,11 +33,11 @@ __device__ __forceinline__ void rgb_to_lab(const float rgb[3], float lab[3]) {
     float lin[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)   // torch_backend.py:28-29
-        lin[c] = rgb[c] > 0.04045f ? fast_pow((rgb[c] + 0.055f) / 1.055f, 2.4f) : rgb[c] / 12.92f;
+        lin[c] = rgb[c] > 0.04045f ? fast_pow((rgb[c] + 0.055f) * (1.0f / 1.055f), 2.4f) : rgb[c] * (1.0f / 12.92f);
     // torch_backend.py:32-38
-    const float x = (0.412453f * lin[0] + 0.357580f * lin[1] + 0.180423f * lin[2]) / 0.95047f;
+    const float x = (0.412453f * lin[0] + 0.357580f * lin[1] + 0.180423f * lin[2]) * (1.0f / 0.95047f);
     const float y = (0.212671f * lin[0] + 0.715160f * lin[1] + 0.072169f * lin[2]);
-    const float z = (0.019334f * lin[0] + 0.119193f * lin[1] + 0.950227f * lin[2]) / 1.08883f;
+    const float z = (0.019334f * lin[0] + 0.119193f * lin[1] + 0.950227f * lin[2]) * (1.0f / 1.08883f);
     const float xyz[3] = {x, y, z};
     float f[3];
 #pragma unroll
@@ -47,11 +48,11 @@ __device__ __forceinline__ void rgb_to_lab(const float rgb[3], float lab[3]) {
     lab[2] = 200.0f * (f[1] - f[2]) + 128.0f;       // :53
 }
 
-__device__ __forceinline__ float f_inv(float t) { return t > 0.2068966f ? t * t * t : (t - 16.0f / 116.0f) / 7.787f; }   // :78-80
+__device__ __forceinline__ float f_inv(float t) { return t > 0.2068966f ? t * t * t : (t - 16.0f / 116.0f) * (1.0f / 7.787f); }   // :78-80
 
 __device__ __forceinline__ void lab_to_rgb(const float lab[3], float rgb[3]) {
-    const float l = lab[0] / 2.55f, a = lab[1] - 128.0f, b = lab[2] - 128.0f;   // :70-72
-    const float fy = (l + 16.0f) / 116.0f, fx = a / 500.0f + fy, fz = fy - b / 200.0f;
+    const float l = lab[0] * (1.0f / 2.55f), a = lab[1] - 128.0f, b = lab[2] - 128.0f;   // :70-72
+    const float fy = (l + 16.0f) * (1.0f / 116.0f), fx = a * (1.0f / 500.0f) + fy, fz = fy - b * (1.0f / 200.0f);
     const float x = f_inv(fx) * 0.95047f, y = f_inv(fy), z = f_inv(fz) * 1.08883f;
     const float lin[3] = {3.2404542f * x - 1.5371385f * y - 0.4985314f * z, -0.9692660f * x + 1.8760108f * y + 0.0415560f * z,
                           0.0556434f * x - 0.2040259f * y + 1.0572252f * z};   // :89-91
@@ -122,12 +123,32 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
     }
     __syncthreads();
     if (!last) return;
-    // last workgroup: sum the partials in index order (deterministic), finish mean / unbiased std
-    if (threadIdx.x < kSums) {
-        double s = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&partial[(int64_t)b * kSums + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        red[0][threadIdx.x] = s;
-        if (sums_out) sums_out[threadIdx.x] = s;     // raw shifted sums for a cross-rank all-reduce
+    // last workgroup: every thread sums the partials of the workgroups b = t, t+256, ... (in that order), then a fixed
+    // reduction tree joins the threads -- deterministic for a given grid, and the loads run in parallel instead of
+    // one dependent chain over all workgroups
+    {
+        double mine[kSums];
+#pragma unroll
+        for (int k = 0; k < kSums; ++k) mine[k] = 0.0;
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += kStreamThreads) {
+#pragma unroll
+            for (int k = 0; k < kSums; ++k) mine[k] += __hip_atomic_load(&partial[(int64_t)b * kSums + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSums; ++k) {
+            const double w = wave_sum(mine[k]);
+            if (lane_id() == 0) red[wave][k] = w;
+        }
+        __syncthreads();
+        double total = 0.0;
+        if (threadIdx.x < kSums)
+            for (int w = 0; w < kStreamThreads / kWave; ++w) total += red[w][threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < kSums) {
+            red[0][threadIdx.x] = total;
+            if (sums_out) sums_out[threadIdx.x] = total;     // raw shifted sums for a cross-rank all-reduce
+        }
     }
     __syncthreads();
     if (threadIdx.x < 3) {
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restri
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         mu[c] = st->mean[c];
-        sd_eps[c] = st->stdv[c] + 1e-8f;     // :349  (divide, not reciprocal-multiply, below)
+        sd_eps[c] = 1.0f / (st->stdv[c] + 1e-8f);     // :349  (one division per channel, reused for every pixel)
         rs[c] = ref_std[c];
         rm[c] = ref_mean[c];
     }
@@ -172,7 +193,7 @@ __global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restri
             float lab[3], back[3];
             rgb_to_lab(rgb, lab);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) lab[c] = ((lab[c] - mu[c]) / sd_eps[c]) * rs[c] + rm[c];   // :349
+            for (int c = 0; c < 3; ++c) lab[c] = ((lab[c] - mu[c]) * sd_eps[c]) * rs[c] + rm[c];   // :349
             lab_to_rgb(lab, back);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {

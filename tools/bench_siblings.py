@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Timing of the sibling paths on the BASELINE.json shapes (not the headline bench):
+   histogram matching 64x3x1024x1024 uint8 (configs[2]), Reinhard 64x3x512x512 fp32 and 1x3x512x512 fp32
+   (configs[0]), Macenko 256x3x224x224 bf16 through StainNormalizerTransform (configs[4], one GPU's share).
+Prints one JSON object per workload with megapixels/s and the fraction of the 8 TB/s HBM peak on the
+algorithmic bytes (one read + one write of every pixel)."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from stainx_amd import HistogramMatching, Reinhard, StainNormalizerTransform, synth  # noqa: E402
+
+dev = torch.device("cuda:0")
+steps, warmup = 50, 10
+
+
+def timed(fn):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    return sum(ms) / len(ms), min(ms)
+
+
+def report(name, pixels, bytes_per_px, ms_mean, ms_min):
+    gbs = pixels * bytes_per_px / (ms_mean * 1e-3) / 1e9
+    print(json.dumps({"workload": name, "megapixels_per_s": round(pixels / 1e6 / (ms_mean * 1e-3), 1), "ms_per_call": round(ms_mean, 4), "ms_min": round(ms_min, 4),
+                      "algorithmic_bytes_per_px": bytes_per_px, "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / 8000, 4)}), flush=True)
+
+
+# histogram matching, config 3
+g = torch.Generator().manual_seed(43)
+src = (torch.rand(64, 3, 1024, 1024, generator=g) * 255).round().to(torch.uint8).to(dev)
+ref = synth.noise_u8((1, 3, 1024, 1024), 42).to(dev)
+hm = HistogramMatching(device=dev).fit(ref)
+report("HistogramMatching.transform 64x3x1024x1024 u8", 64 * 1024 * 1024, 6, *timed(lambda: hm.transform(src)))
+del src
+
+# Reinhard
+x = synth.as_dtype(synth.noise_u8((64, 3, 512, 512), 43), torch.float32).to(dev)
+rn = Reinhard(device=dev).fit(synth.as_dtype(synth.noise_u8((1, 3, 512, 512), 42), torch.float32).to(dev))
+report("Reinhard.transform 64x3x512x512 f32", 64 * 512 * 512, 24, *timed(lambda: rn.transform(x)))
+x1 = x[:1].contiguous()
+report("Reinhard.fit+transform 1x3x512x512 f32 (configs[0] shape)", 512 * 512, 24, *timed(lambda: rn.fit(x1).transform(x1)))
+del x
+
+# Macenko bf16 through the module, config 5 (one GPU's share of the batch)
+tiles = synth.as_dtype(synth.he_batch(256, 224, 224), torch.bfloat16).to(dev)
+t = StainNormalizerTransform(method="macenko", mode="reference", reference=synth.as_dtype(synth.reference_tile(224, 224), torch.bfloat16).to(dev))
+report("StainNormalizerTransform(macenko, reference) 256x3x224x224 bf16", 256 * 224 * 224, 12, *timed(lambda: t(tiles)))
