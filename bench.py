@@ -32,6 +32,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_FILE = ROOT / "profiles" / "r01_macenko_cfg2_hbm_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see DESIGN.md
 TILES, HEIGHT, WIDTH = 64, 512, 512
 BYTES_PER_PIXEL = 24           # fp32 in + fp32 out, 3 channels
 
@@ -41,7 +42,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=25)
-    ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles of the workload the CPU baseline is timed on")
+    ap.add_argument("--cpu-tiles", type=int, default=32, help="tiles of the workload the CPU baseline is timed on")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     return ap.parse_args()
 
@@ -50,14 +51,26 @@ def cpu_baseline(n_tiles: int, x_cpu: torch.Tensor, he, max_c) -> dict:
     """Oracle (port of the reference CPU path) on the first n_tiles tiles of the workload."""
     from oracle import stain_oracle as so
 
+    from threadpoolctl import threadpool_limits
+
     sample = x_cpu[:n_tiles].numpy()
-    so.macenko_transform(sample[:1], he, max_c)          # warm-up
-    t0 = time.perf_counter()
-    so.macenko_transform(sample, he, max_c)
-    dt = time.perf_counter() - t0
+    with threadpool_limits(limits=1):                    # one core, so that `cores` is what was really used
+        so.macenko_transform(sample[:1], he, max_c)      # warm-up
+        t0 = time.perf_counter()
+        so.macenko_transform(sample, he, max_c)
+        dt = time.perf_counter() - t0
     return {"value": round(n_tiles * HEIGHT * WIDTH / 1e6 / dt, 3), "unit": "megapixels/s", "cores": 1, "kind": "port",
-            "sample": f"{n_tiles} of the {TILES} tiles (512x512 fp32), numpy oracle single-threaded, {dt:.2f} s; host has {os.cpu_count()} cores",
+            "sample": f"{n_tiles} of the {TILES} tiles (512x512 fp32), numpy oracle on one core (BLAS threads limited to 1), {dt:.2f} s; host has {os.cpu_count()} cores",
             "reference_note": "true reference (stainx 0.1.4 backend=torch, 8 cores, build container): 11.4 megapixels/s (BASELINE.md)"}
+
+
+def measured_traffic():
+    """HBM bytes of one transform call from the committed PMC run of this same command (rocprofv3 cannot be nested
+    inside the timed process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes.  None if absent."""
+    try:
+        return int(json.loads(TRAFFIC_FILE.read_text())["total_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main() -> None:
@@ -127,9 +140,11 @@ def main() -> None:
             "config": {"workload": "Macenko reference-mode transform, 64x3x512x512 fp32 per GPU (BASELINE configs[1])",
                        "tiles_per_gpu": TILES, "height": HEIGHT, "width": WIDTH, "parallelism": f"tiles sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "algorithmic_bytes_per_launch": pixels * BYTES_PER_PIXEL,
-                         "kernel": "all launches of one sx_macenko_transform call", "device_ms_per_call": round(dev_ms, 4),
-                         "device_ms_min": round(min(step_ms), 4)},
+                         "traffic": measured_traffic(), "algorithmic_bytes_per_launch": pixels * BYTES_PER_PIXEL,
+                         "kernel": "all 7 launches of one sx_macenko_transform call (stats, plane, bracket<phi>, stain, bracket<conc>, scale, reconstruct)",
+                         "device_ms_per_call": round(dev_ms, 4), "device_ms_min": round(min(step_ms), 4),
+                         "dominant_kernel": {"name": "reconstruct_kernel", "algorithmic_bytes": pixels * BYTES_PER_PIXEL,
+                                             "note": "the only launch that moves the full 24 B/px; its rocprofv3 average is in profiles/r01_*_kernel_stats.csv"}},
         }
         if world == 1 and not args.no_cpu:
             he = norm._stain_matrix.cpu().numpy()

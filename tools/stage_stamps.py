@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
 from stainx_amd import synth
 from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 dev = torch.device("cuda:0")
