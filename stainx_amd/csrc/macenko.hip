@@ -29,7 +29,7 @@ namespace sx {
 namespace macenko {
 
 constexpr int kSample = 4096;          // strided sample per tile
-constexpr int kCap = 32768;            // candidate keys per selection slot
+constexpr int kMinCap = 32768;         // candidate keys per selection slot: at least this, 1/16 of the group's pixels for big groups
 constexpr int kIters = 8;              // pixel packs per lane per work item
 constexpr int kChunk = kStreamThreads * 4 * kIters;   // 8192 pixels per work item
 constexpr int kSlots = 4;              // 0: phi@1  1: phi@99  2: C0@99  3: C1@99
@@ -79,12 +79,13 @@ struct Geometry {
     int vec;                      // 1: 4-pixel packs (16-byte loads), 0: scalar accesses
     int pooled;                   // 1: one group over all tiles (fit), 0: one group per tile
     int sample_stride, sample_count;   // sample j = pixel j*stride of the group, j < count
+    uint32_t cap;                 // candidate keys per selection slot
 };
 
 struct Workspace {
     GroupState* state;
     double* partial;              // [n_tiles*blocks_per_tile][kMoments]
-    uint32_t* cand;               // [groups][kSlots][kCap]
+    uint32_t* cand;               // [groups][kSlots][cap]
     uint32_t* block_hist;         // [n_tiles*blocks_per_tile][2][256] bracket-relative histograms of a stage's candidates
     float* sample_od;             // [groups][3][kSample] optical density of the strided sample
 };
@@ -93,11 +94,23 @@ __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a -
 
 static int blocks_per_tile_for(int64_t pixels) { return (int)((pixels + kChunk - 1) / kChunk); }
 
+// Candidate capacity per slot of a group of `count` pixels: brackets hold ~2-3 % of the pixels.
+static uint32_t cap_for(int64_t count) {
+    int64_t cap = kMinCap;
+    while (cap < count / 16) cap *= 2;
+    return (uint32_t)cap;
+}
+// A batch of n tiles is used as n groups of P pixels (transform) or as ONE group of n*P pixels (pooled fit); the
+// candidate area is sized for the larger of the two layouts.
+static size_t cand_words(int64_t n_tiles, int64_t pixels) {
+    return std::max((size_t)n_tiles * cap_for(pixels), (size_t)cap_for(n_tiles * pixels)) * kSlots;
+}
+
 static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
     const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
     size_t total = align_up(sizeof(GroupState) * n, 256);
     total += align_up(sizeof(double) * kMoments * b * n, 256);
-    total += align_up(sizeof(uint32_t) * kSlots * kCap * n, 256);
+    total += align_up(sizeof(uint32_t) * cand_words(n_tiles, pixels), 256);
     total += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     total += align_up(sizeof(float) * 3 * kSample * n, 256);
     return total;
@@ -112,7 +125,7 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     w.partial = reinterpret_cast<double*>(p);
     p += align_up(sizeof(double) * kMoments * b * n, 256);
     w.cand = reinterpret_cast<uint32_t*>(p);
-    p += align_up(sizeof(uint32_t) * kSlots * kCap * n, 256);
+    p += align_up(sizeof(uint32_t) * cand_words(n_tiles, pixels), 256);
     w.block_hist = reinterpret_cast<uint32_t*>(p);
     p += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     w.sample_od = reinterpret_cast<float*>(p);
@@ -613,6 +626,9 @@ __device__ __forceinline__ GroupPixels group_pixels(const Geometry& g, int group
     return gp;
 }
 
+// Offset of sample j inside its stride-long cell: top `shift` bits of a multiplicative hash of j.
+__device__ __forceinline__ uint32_t sample_offset(uint32_t j, int shift) { return shift ? (j * 0x9E3779B1u) >> (32 - shift) : 0u; }
+
 // ------------------------------------------------------------------------------------------------
 // streaming stage S1: raw moments of the OD vectors of one work item (+ the sample's OD on the way)
 // ------------------------------------------------------------------------------------------------
@@ -656,12 +672,12 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
                 a[k] += pr[k];
                 m[k] = fmaf(keep, pr[k], m[k]);
             }
-            if (((gpos + (uint32_t)i) & mask) == 0u) {
-                const uint32_t j = (gpos + (uint32_t)i) >> shift;
-                if (j < sample_count) {
+            // sample j sits in [j*stride, (j+1)*stride) at a hashed offset (a fixed offset would alias with the image
+            // width: stride 1024 on a 2048-wide tile samples two columns only)
+            const uint32_t pos = gpos + (uint32_t)i, j = pos >> shift;
+            if ((pos & mask) == sample_offset(j, shift) && j < sample_count) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od[c]);
-                }
+                for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od[c]);
             }
         }
     }
@@ -735,8 +751,8 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 
     const bool use_all = kConc ? true : (rec.use_all != 0);
     const uint32_t lo_a = rec.lo[0], hi_a = rec.hi[0], lo_b = rec.lo[1], hi_b = rec.hi[1];
-    uint32_t* cand_a = ws.cand + ((size_t)group * kSlots + s0) * kCap;
-    uint32_t* cand_b = cand_a + kCap;
+    uint32_t* cand_a = ws.cand + ((size_t)group * kSlots + s0) * g.cap;
+    uint32_t* cand_b = cand_a + g.cap;
     uint32_t below_a = 0, below_b = 0;
 
     for (int64_t phase_begin = p_begin; phase_begin < p_end; phase_begin += kPhase) {
@@ -779,7 +795,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             const double origin = rec.bin_origin[which], scale = rec.bin_scale[which];
             for (uint32_t i = threadIdx.x; i < n_local; i += TPB) {
                 const uint32_t key = sh->keys[which][i];
-                if (base + i < (uint32_t)kCap) put(&dst[base + i], key);
+                if (base + i < g.cap) put(&dst[base + i], key);
                 atomicAdd(&sh->hist[which][bin_of(key, origin, scale)], 1u);
             }
         }
@@ -999,7 +1015,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
         ncand[j] = get(&st.ncand[slot]);
         const unsigned long long below = get(&st.below[slot]);
         want_all[j] = get(&st.rank[slot]);
-        ok[j] = ncand[j] <= (uint32_t)kCap && want_all[j] >= below && want_all[j] - below < ncand[j];
+        ok[j] = ncand[j] <= g.cap && want_all[j] >= below && want_all[j] - below < ncand[j];
         want_in[j] = ok[j] ? want_all[j] - below : 0ull;
         origin[j] = get(&rec->bin_origin[j]);
         scale[j] = get(&rec->bin_scale[j]);
@@ -1033,7 +1049,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (!ok[j]) continue;
-        const uint32_t* cand = ws.cand + ((size_t)group * kSlots + first_slot + j) * kCap;
+        const uint32_t* cand = ws.cand + ((size_t)group * kSlots + first_slot + j) * g.cap;
         const uint32_t b = sh->bin[j];
         for (uint32_t base = threadIdx.x; base < ncand[j]; base += blockDim.x * 8) {
             uint32_t k[8];
@@ -1081,7 +1097,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
         if (ok[j] && sh->count[j] <= (uint32_t)kShortList) {
             key_out[j] = sh->result[j];        // ranked above, both lists side by side
         } else if (ok[j]) {      // crowded bin: radix rounds over the candidates
-            const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * kCap;
+            const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * g.cap;
             if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
             key_out[j] = radix_select_stream((unsigned long long)ncand[j], want_in[j], [cand](unsigned long long i, uint32_t& k) { k = get(&cand[i]); return true; }, sh);
         } else {                 // the bracket did not hold: recompute every key of the group
@@ -1394,6 +1410,7 @@ static void set_sampling(Geometry& g) {
     while ((count + stride - 1) / stride > kSample) stride *= 2;
     g.sample_stride = (int)stride;
     g.sample_count = (int)std::min<int64_t>(kSample, (count + stride - 1) / stride);
+    g.cap = cap_for(count);
 }
 
 template <typename T, int V>
@@ -1506,7 +1523,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -1524,7 +1541,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -1551,7 +1568,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -1573,7 +1590,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {

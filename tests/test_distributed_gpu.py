@@ -36,6 +36,16 @@ def test_world_size_one_matches_fused_paths(golden):
         np.testing.assert_allclose(max_c.cpu().numpy(), g[f"{tag}_max_c"], rtol=1e-4, atol=0)
         he2, mc2 = MacenkoHIP(dev).compute_reference_stain_matrix(tiles)
         assert torch.equal(he, he2) and torch.equal(max_c, mc2)          # radix-select fit == bracketed fit, bit for bit
+    # a pooled group far larger than one tile (2.1 M pixels): the candidate buffers scale with the group, no slow path
+    many = synth.he_batch(32, 256, 256, seed0=400, scale_step=0.004).to(dev)
+    be = MacenkoHIP(dev)
+    he_b, mc_b = be.compute_reference_stain_matrix(many)
+    assert int(be.tile_params(1)["fell_back"][0]) & 0xF == 0        # no whole-group select
+    he_d, mc_d = sxd.macenko_fit_pooled(many)
+    assert torch.equal(he_b, he_d) and torch.equal(mc_b, mc_d)
+    he_o, mc_o = so.macenko_fit(many.cpu().numpy(), signs="positive_sum")
+    np.testing.assert_allclose(he_b.cpu().numpy(), he_o, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(mc_b.cpu().numpy(), mc_o, rtol=1e-4, atol=0)
     noise = synth.noise_u8((3, 3, 67, 45), 43).to(dev)
     ref = synth.noise_u8((1, 3, 67, 45), 42).to(dev)
     rb = ReinhardHIP(dev)

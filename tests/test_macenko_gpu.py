@@ -160,8 +160,9 @@ def test_bracket_fallback_path_is_exact(dev):
     be = _backend(dev)
     ref_he, ref_mc = so.macenko_fit(synth.reference_tile(64, 64).numpy())
     tile = synth.he_batch(1, 1024, 1024, seed0=55)
-    # 16 distinct pixels, 65536 copies each: every inclusive bracket holds a whole tie group > 32768 candidates
-    blocky = tile[:, :, ::256, ::256].repeat_interleave(256, dim=2).repeat_interleave(256, dim=3).contiguous()
+    # 8 distinct pixels, 131072 copies each: every inclusive bracket holds a whole tie group larger than the
+    # candidate buffer of a 1024x1024 tile (65536 keys)
+    blocky = tile[:, :, ::512, ::256].repeat_interleave(512, dim=2).repeat_interleave(256, dim=3).contiguous()
     for x in (blocky, synth.as_dtype(blocky, torch.float32)):
         out = be.transform(x.to(dev), torch.from_numpy(ref_he), torch.from_numpy(ref_mc))
         p = be.tile_params(1)
@@ -191,3 +192,60 @@ def test_argument_errors(dev):
     lib = _native.require()
     assert lib.sx_macenko_transform(None, None, 3, 1, 8, 8, None, None, 0, None, 0, None) != 0
     assert "null" in _native.last_error() or "workspace" in _native.last_error()
+
+
+def test_stream_order_and_graph_capture(dev):
+    """The library only enqueues on the caller's stream: it must work on a side stream and be capturable in a
+    HIP graph (no allocation, synchronisation or host read inside the call), and replay must reproduce the bits."""
+    be = _backend(dev)
+    ref_he, ref_mc = so.macenko_fit(synth.reference_tile(64, 64).numpy())
+    sm, tmc = torch.from_numpy(ref_he).to(dev), torch.from_numpy(ref_mc).to(dev)
+    x = synth.as_dtype(synth.he_batch(4, 128, 128, seed0=77), torch.float32).to(dev)
+    eager = be.transform(x, sm, tmc)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        on_side = be.transform(x, sm, tmc)
+    side.synchronize()
+    assert torch.equal(on_side, eager)
+    graph = torch.cuda.CUDAGraph()
+    static_in = x.clone()
+    with torch.cuda.graph(graph):
+        static_out = be.transform(static_in, sm, tmc)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, eager)
+    static_in.copy_(synth.as_dtype(synth.he_batch(4, 128, 128, seed0=78), torch.float32))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, be.transform(static_in, sm, tmc))
+
+
+def test_large_tile_and_non_contiguous_input(dev):
+    be = _backend(dev)
+    ref_he, ref_mc = so.macenko_fit(synth.reference_tile(64, 64).numpy())
+    big = synth.as_dtype(synth.he_batch(1, 2048, 2048, seed0=5), torch.float32)       # the reference tests go up to 2048x2048
+    out = be.transform(big.to(dev), torch.from_numpy(ref_he), torch.from_numpy(ref_mc))
+    want = so.macenko_transform(big.numpy(), ref_he, ref_mc)
+    assert np.abs(out.cpu().numpy() - want).max() <= TOL_255
+    assert int(be.tile_params(1)["fell_back"][0]) & 0xF == 0        # no whole-tile select (a crowded bin may use the candidate radix)
+    # a channels-last view is made contiguous by the wrapper; the result equals the contiguous call
+    tiles = synth.as_dtype(synth.he_batch(2, 64, 64, seed0=9), torch.float32).to(dev)
+    view = tiles.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    assert not view.is_contiguous()
+    assert torch.equal(be.transform(view, torch.from_numpy(ref_he), torch.from_numpy(ref_mc)), be.transform(tiles, torch.from_numpy(ref_he), torch.from_numpy(ref_mc)))
+
+
+def test_crowded_bin_path_is_exact(dev):
+    """Heavy ties inside a bracket that still fits the candidate buffer: the picked histogram bin holds more than
+    512 equal keys, so the per-tile stage must fall back to radix rounds over the candidates (fell_back bits 4..7)."""
+    be = _backend(dev)
+    ref_he, ref_mc = so.macenko_fit(synth.reference_tile(64, 64).numpy())
+    tile = synth.he_batch(1, 512, 512, seed0=56)
+    blocky = tile[:, :, ::32, ::32].repeat_interleave(32, dim=2).repeat_interleave(32, dim=3).contiguous()   # 256 distinct pixels x 1024 copies
+    out = be.transform(blocky.to(dev), torch.from_numpy(ref_he), torch.from_numpy(ref_mc))
+    p = be.tile_params(1)
+    assert int(p["fell_back"][0]) & 0xF0, f"expected a candidate radix select, got {int(p['fell_back'][0]):#x}"
+    want, params = so.macenko_transform(blocky.numpy(), ref_he, ref_mc, return_params=True)
+    assert np.abs(out.cpu().numpy().astype(int) - want.astype(int)).max() <= 1
+    np.testing.assert_allclose(p["max_c"][0].numpy(), params[0]["max_c"], rtol=1e-4)
