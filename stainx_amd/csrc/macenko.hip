@@ -35,7 +35,7 @@ constexpr int kChunk = kStreamThreads * 4 * kIters;   // 8192 pixels per work it
 constexpr int kSlots = 4;              // 0: phi@1  1: phi@99  2: C0@99  3: C1@99
 constexpr int kMoments = 20;           // [cnt,sx,sy,sz,xx,xy,xz,yy,yz,zz] masked, then all pixels
 constexpr int kShortList = 512;        // keys of one histogram bin gathered for rank counting
-constexpr int kPhasePixels = 2048;     // pixels between two flushes of the LDS candidate queues
+constexpr int kPhasePixels = 4096;     // pixels between two flushes of the LDS candidate queues
 
 constexpr float kBeta = 0.15f;         // torch_backend.py:542
 constexpr float kIo = 240.0f;          // torch_backend.py:541

@@ -58,3 +58,12 @@ del x
 tiles = synth.as_dtype(synth.he_batch(256, 224, 224), torch.bfloat16).to(dev)
 t = StainNormalizerTransform(method="macenko", mode="reference", reference=synth.as_dtype(synth.reference_tile(224, 224), torch.bfloat16).to(dev))
 report("StainNormalizerTransform(macenko, reference) 256x3x224x224 bf16", 256 * 224 * 224, 12, *timed(lambda: t(tiles)))
+
+# Macenko on the config-2 shape for the other input dtypes (algorithmic bytes: u8 6 B/px, bf16/f16 12 B/px)
+from stainx_amd import Macenko  # noqa: E402
+
+u8 = synth.he_batch(64, 512, 512)
+mk = Macenko(device=dev).fit(synth.reference_tile(512, 512).to(dev))
+for name, dt, bpp in (("u8", torch.uint8, 6), ("bf16", torch.bfloat16, 12), ("f16", torch.float16, 12), ("f32", torch.float32, 24)):
+    xin = synth.as_dtype(u8, dt).to(dev)
+    report(f"Macenko.transform 64x3x512x512 {name}", 64 * 512 * 512, bpp, *timed(lambda: mk.transform(xin)))
