@@ -46,8 +46,8 @@ template <> struct Elem<double> {
     static __device__ __forceinline__ double store(float v) { return (double)v; }
 };
 
-// A naturally aligned pack of V elements moved by one load/store instruction
-// (f32 x4 = 16 B/lane, bf16/f16 x4 = 8 B, u8 x4 = 4 B, f64 x4 = 2 x 16 B).
+// A naturally aligned pack of V elements; the streaming kernels use 16-byte packs
+// (f32 x4, bf16/f16 x8, u8 x16, f64 x2) or single elements when the tile is not pack-aligned.
 template <typename T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
 
 template <typename T, int V>
@@ -58,6 +58,22 @@ __device__ __forceinline__ void load_unit(const T* __restrict__ p, float (&out)[
         const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(p);
 #pragma unroll
         for (int i = 0; i < V; ++i) out[i] = Elem<T>::load(pk.v[i]);
+    }
+}
+
+// Same pack, but uint8 pixels stay integer-valued floats 0..255 (callers that fold the /255 into their own
+// arithmetic, like the optical density of the Macenko path).
+template <typename T> __device__ __forceinline__ float raw_value(T v) {
+    if constexpr (sizeof(T) == 1) return (float)v; else return Elem<T>::load(v);
+}
+template <typename T, int V>
+__device__ __forceinline__ void load_raw(const T* __restrict__ p, float (&out)[V]) {
+    if constexpr (V == 1) {
+        out[0] = raw_value<T>(p[0]);
+    } else {
+        const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(p);
+#pragma unroll
+        for (int i = 0; i < V; ++i) out[i] = raw_value<T>(pk.v[i]);
     }
 }
 
@@ -77,29 +93,20 @@ __device__ __forceinline__ void store_pack(T* __restrict__ p, const T (&vals)[V]
 // by this library, and a non-temporal store does not leave a dirty line behind for the next reader to wait on.
 template <typename T, int V>
 __device__ __forceinline__ void store_pack_stream(T* __restrict__ p, const T (&vals)[V]) {
-    if constexpr (V == 1 && (sizeof(T) == 4 || sizeof(T) == 8)) {
-        if constexpr (sizeof(T) == 4) {
-            unsigned v;
-            __builtin_memcpy(&v, vals, 4);
-            __builtin_nontemporal_store(v, reinterpret_cast<unsigned*>(p));
-        } else {
-            unsigned long long v;
-            __builtin_memcpy(&v, vals, 8);
-            __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(p));
-        }
-    } else if constexpr (V == 1) {
-        p[0] = vals[0];
-    } else if constexpr (sizeof(T) * V == 16) {
+    constexpr int kBytes = (int)sizeof(T) * V;
+    if constexpr (kBytes % 16 == 0) {
         typedef float f4 __attribute__((ext_vector_type(4)));
-        f4 v;
-        __builtin_memcpy(&v, vals, 16);
-        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
-    } else if constexpr (sizeof(T) * V == 8) {
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        f2 v;
+#pragma unroll
+        for (int piece = 0; piece < kBytes / 16; ++piece) {
+            f4 v;
+            __builtin_memcpy(&v, reinterpret_cast<const char*>(vals) + 16 * piece, 16);
+            __builtin_nontemporal_store(v, reinterpret_cast<f4*>(reinterpret_cast<char*>(p) + 16 * piece));
+        }
+    } else if constexpr (kBytes == 8) {
+        unsigned long long v;
         __builtin_memcpy(&v, vals, 8);
-        __builtin_nontemporal_store(v, reinterpret_cast<f2*>(p));
-    } else if constexpr (sizeof(T) * V == 4) {
+        __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(p));
+    } else if constexpr (kBytes == 4) {
         unsigned v;
         __builtin_memcpy(&v, vals, 4);
         __builtin_nontemporal_store(v, reinterpret_cast<unsigned*>(p));

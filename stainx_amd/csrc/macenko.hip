@@ -30,8 +30,8 @@ namespace macenko {
 
 constexpr int kSample = 4096;          // strided sample per tile
 constexpr int kMinCap = 32768;         // candidate keys per selection slot: at least this, 1/16 of the group's pixels for big groups
-constexpr int kIters = 8;              // pixel packs per lane per work item
-constexpr int kChunk = kStreamThreads * 4 * kIters;   // 8192 pixels per work item
+constexpr int kChunk = 8192;           // pixels per work item (32 per lane of a 256-thread workgroup)
+template <typename T> struct PackOf { static constexpr int n = 16 / (int)sizeof(T); };   // pixels per 16-byte load: f32 4, bf16/f16 8, u8 16, f64 2
 constexpr int kSlots = 4;              // 0: phi@1  1: phi@99  2: C0@99  3: C1@99
 constexpr int kMoments = 20;           // [cnt,sx,sy,sz,xx,xy,xz,yy,yz,zz] masked, then all pixels
 constexpr int kShortList = 512;        // keys of one histogram bin gathered for rank counting
@@ -147,8 +147,11 @@ template <typename U> __device__ __forceinline__ U get(const U* p) { return *p; 
 // ------------------------------------------------------------------------------------------------
 // OD = -log((x*255+1)/240) (torch_backend.py:550) evaluated as ln240 - ln2*log2(x*255+1):
 // one fma, v_log_f32, one fma.  Differs from the reference's mul/add/div/log chain by ~1e-7 absolute.
-__device__ __forceinline__ float optical_density(float unit) {
-    const float t = fmaf(unit, 255.0f, 1.0f);
+// `raw` is the unit value for float inputs and the integer grey level for uint8 (the reference's u/255*255 is u
+// up to one rounding).
+template <typename T>
+__device__ __forceinline__ float optical_density(float raw) {
+    const float t = sizeof(T) == 1 ? raw + 1.0f : fmaf(raw, 255.0f, 1.0f);
     return fmaf(-kLn2, __log2f(t), kLnIo);
 }
 
@@ -198,7 +201,7 @@ template <typename T>
 __device__ __forceinline__ void load_od_scalar(const T* __restrict__ images, int64_t pixels, int64_t tile, int64_t p, float od[3]) {
     const T* base = images + tile * 3 * pixels + p;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) od[c] = optical_density(Elem<T>::load(base[c * pixels]));
+    for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(raw_value<T>(base[c * pixels]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,10 +514,12 @@ __device__ void sample_brackets(TileScratch* sh, int n_sets, unsigned long long 
     for (int s = 0; s < 2; ++s) {
         long long lo_r, hi_r;
         bracket_ranks(m_valid, n_total, k0[s], lo_r, hi_r);
-        want[2 * s] = m_valid > 0 && lo_r >= 0;
-        want[2 * s + 1] = m_valid > 0 && hi_r < m_valid;
-        rank[2 * s] = (unsigned long long)(lo_r < 0 ? 0 : lo_r);
-        rank[2 * s + 1] = (unsigned long long)(hi_r < 0 ? 0 : hi_r);
+        // a bracket rank beyond the sample is clamped to the sample's extreme: the bracket stays closed (an open side
+        // would gather the whole tail, ~1 % of the tile); the wanted element lying beyond all 4096 samples is a
+        // 1e-18 event and, like every bracket miss, is caught by the count check and repaired by the slow path
+        want[2 * s] = want[2 * s + 1] = m_valid > 0;
+        rank[2 * s] = (unsigned long long)min(max(lo_r, 0ll), (long long)m_valid - 1);
+        rank[2 * s + 1] = (unsigned long long)min(max(hi_r, 0ll), (long long)m_valid - 1);
     }
     for (int set = 0; set < n_sets; ++set)
         for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
@@ -658,13 +663,13 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
         float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
         const uint32_t gpos = group_offset + (uint32_t)p;      // position inside the group; samples sit at multiples of stride
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float od[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
+            for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
             const float keep = od_selected(od, false) ? 1.0f : 0.0f;
             const float pr[10] = {1.0f, od[0], od[1], od[2], od[0] * od[0], od[0] * od[1], od[0] * od[2], od[1] * od[1], od[1] * od[2], od[2] * od[2]};
 #pragma unroll
@@ -760,12 +765,12 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
         for (int64_t p = phase_begin + (int64_t)threadIdx.x * V; p < phase_end; p += (int64_t)TPB * V) {
             float u[3][V];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+            for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float od[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
+                for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
                 const bool valid = od_selected(od, use_all);
                 uint32_t key_a, key_b;
                 if constexpr (kConc) {
@@ -844,13 +849,13 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
         float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
         O res[3][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float od[3], c0, c1;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
+            for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
             concentration(od, pinv, c0, c1);
             c0 *= s0;                                                   // :453
             c1 *= s1;
@@ -1315,12 +1320,12 @@ __global__ __launch_bounds__(kStreamThreads) void dfit_histogram_kernel(const T*
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
         float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float od[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = optical_density(u[c][i]);
+            for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
             uint32_t ka, kb;
             if (stage) {
                 float c0, c1;
@@ -1442,28 +1447,30 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     Geometry g = g0;
     const bool u8_unit = unit && sizeof(T) == 1;
     const size_t out_elem = u8_unit ? sizeof(float) : sizeof(T);
-    const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4) && aligned_for(out, out_elem * 4);
+    constexpr int W = PackOf<T>::n;
+    const bool vec = (g.pixels % W == 0) && aligned_for(images, 16) && aligned_for(out, out_elem * W);
     g.vec = vec ? 1 : 0;
     set_sampling(g);
     const T* in = static_cast<const T*>(images);
     if constexpr (sizeof(T) == 1) {
         if (u8_unit) {
-            return vec ? run_transform<T, float, 4>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream)
+            return vec ? run_transform<T, float, W>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream)
                        : run_transform<T, float, 1>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream);
         }
     }
-    return vec ? run_transform<T, T, 4>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream)
+    return vec ? run_transform<T, T, W>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream)
                : run_transform<T, T, 1>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream);
 }
 
 template <typename T>
 static int fit_typed(const void* images, const Geometry& g0, const Workspace& ws, float* he_out, float* max_c_out, hipStream_t stream) {
     Geometry g = g0;
-    const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4);
+    constexpr int W = PackOf<T>::n;
+    const bool vec = (g.pixels % W == 0) && aligned_for(images, 16);
     g.vec = vec ? 1 : 0;
     set_sampling(g);
     const T* in = static_cast<const T*>(images);
-    return vec ? run_estimate<T, 4>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream)
+    return vec ? run_estimate<T, W>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream)
                : run_estimate<T, 1>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream);
 }
 
@@ -1471,13 +1478,14 @@ static int fit_typed(const void* images, const Geometry& g0, const Workspace& ws
 template <typename T>
 static int dfit_moments_typed(const void* images, const Geometry& g0, const Workspace& ws, double* moments, hipStream_t stream) {
     Geometry g = g0;
-    const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4);
+    constexpr int W = PackOf<T>::n;
+    const bool vec = (g.pixels % W == 0) && aligned_for(images, 16);
     g.vec = vec ? 1 : 0;
     set_sampling(g);
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
     if (vec)
-        hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
+        hipLaunchKernelGGL((stats_kernel<T, W>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
     else
         hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
     hipLaunchKernelGGL(dfit_reduce_partials_kernel, dim3(1), dim3(64), 0, stream, ws.partial, (int64_t)grid, moments);
@@ -1487,13 +1495,14 @@ static int dfit_moments_typed(const void* images, const Geometry& g0, const Work
 template <typename T>
 static int dfit_histogram_typed(const void* images, const Geometry& g0, const DFitState* st, int stage, unsigned long long* hist, hipStream_t stream) {
     Geometry g = g0;
-    const bool vec = (g.pixels % 4 == 0) && aligned_for(images, sizeof(T) * 4);
+    constexpr int W = PackOf<T>::n;
+    const bool vec = (g.pixels % W == 0) && aligned_for(images, 16);
     g.vec = vec ? 1 : 0;
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
     if (hipMemsetAsync(hist, 0, 512 * sizeof(unsigned long long), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
     if (vec)
-        hipLaunchKernelGGL((dfit_histogram_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, stage, hist);
+        hipLaunchKernelGGL((dfit_histogram_kernel<T, W>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, stage, hist);
     else
         hipLaunchKernelGGL((dfit_histogram_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, stage, hist);
     return check_launch("macenko dfit histogram");
