@@ -139,6 +139,58 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
+// ---- wave64 scans / reductions on the DPP path -----------------------------------------------------
+// ds_bpermute shuffles cost an LDS round trip each (~100 cycles, six of them in a dependent chain per
+// reduction); DPP row shifts + the two gfx9 row broadcasts stay in the VALU.  Pattern: Hillis-Steele inside
+// each row of 16 (row_shr 1,2,4,8), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lanes
+// without a source keep `identity`.  After it every lane holds the inclusive scan, lane 63 the total.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t identity, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)src, kCtrl, kRowMask, 0xF, false);
+}
+#define SX_DPP_SCAN(x, identity, OP)                               \
+    x = OP(x, dpp_move<0x111, 0xF>(identity, x)); /* row_shr:1 */  \
+    x = OP(x, dpp_move<0x112, 0xF>(identity, x)); /* row_shr:2 */  \
+    x = OP(x, dpp_move<0x114, 0xF>(identity, x)); /* row_shr:4 */  \
+    x = OP(x, dpp_move<0x118, 0xF>(identity, x)); /* row_shr:8 */  \
+    x = OP(x, dpp_move<0x142, 0xA>(identity, x)); /* row_bcast:15 */ \
+    x = OP(x, dpp_move<0x143, 0xC>(identity, x)); /* row_bcast:31 */
+__device__ __forceinline__ uint32_t op_add_u32(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t op_min_u32(uint32_t a, uint32_t b) { return min(a, b); }
+__device__ __forceinline__ uint32_t op_max_u32(uint32_t a, uint32_t b) { return max(a, b); }
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {       // inclusive prefix sum
+    SX_DPP_SCAN(x, 0u, op_add_u32)
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_total_u32(uint32_t x) {      // sum, uniform in every lane
+    SX_DPP_SCAN(x, 0u, op_add_u32)
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+    SX_DPP_SCAN(x, 0xFFFFFFFFu, op_min_u32)
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+    SX_DPP_SCAN(x, 0u, op_max_u32)
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+// doubles go through two 32-bit moves
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_move_f64(double src) {          // identity 0.0
+    const unsigned long long u = (unsigned long long)__double_as_longlong(src);
+    const uint32_t lo = dpp_move<kCtrl, kRowMask>(0u, (uint32_t)u), hi = dpp_move<kCtrl, kRowMask>(0u, (uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_total_f64(double x) {          // fixed order -> deterministic; total in lane 63 only
+    x += dpp_move_f64<0x111, 0xF>(x);
+    x += dpp_move_f64<0x112, 0xF>(x);
+    x += dpp_move_f64<0x114, 0xF>(x);
+    x += dpp_move_f64<0x118, 0xF>(x);
+    x += dpp_move_f64<0x142, 0xA>(x);
+    x += dpp_move_f64<0x143, 0xC>(x);
+    return x;
+}
+
 // Position of this lane among the set lanes of `mask` below it.
 __device__ __forceinline__ uint32_t rank_in_mask(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

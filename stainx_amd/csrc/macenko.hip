@@ -36,6 +36,11 @@ constexpr int kSlots = 4;              // 0: phi@1  1: phi@99  2: C0@99  3: C1@9
 constexpr int kMoments = 20;           // [cnt,sx,sy,sz,xx,xy,xz,yy,yz,zz] masked, then all pixels
 constexpr int kShortList = 512;        // keys of one histogram bin gathered for rank counting
 constexpr int kPhasePixels = 4096;     // pixels between two flushes of the LDS candidate queues
+constexpr int kGroupThreads = 1024;    // per-tile stages: one workgroup per group, as their own launch
+constexpr int kKeys = kSample / kGroupThreads;   // sample keys a thread of a per-tile stage holds in registers
+constexpr int kPrefetchHist = 16;      // work-item histograms a thread fetches up front (2 threads per bin: 32 work items = one 512x512 tile)
+constexpr int kPrefetchCand = 8;       // candidates per slot a thread fetches up front (8192 per slot)
+static_assert(kKeys * kGroupThreads == kSample && kPrefetchCand * kGroupThreads <= kMinCap, "per-tile stage geometry");
 
 constexpr float kBeta = 0.15f;         // torch_backend.py:542
 constexpr float kIo = 240.0f;          // torch_backend.py:541
@@ -397,6 +402,47 @@ __device__ __forceinline__ void scan_pick(const uint32_t* hist, unsigned long lo
     rank_in_bin = r;
 }
 
+// The same for totals below 2^32 (samples, candidates) on the DPP scan; the histogram is 16-byte aligned.
+__device__ __forceinline__ void scan_pick32(const uint32_t* hist, uint32_t rank, uint32_t& digit, uint32_t& rank_in_bin) {
+    const int lane = (int)lane_id();
+    const uint4 h = *reinterpret_cast<const uint4*>(hist + 4 * lane);
+    const uint32_t mine = h.x + h.y + h.z + h.w;
+    const uint32_t incl = wave_scan_u32(mine);
+    const uint64_t over = __ballot(incl > rank);
+    const int owner = over ? (__ffsll((long long)over) - 1) : (kWave - 1);
+    const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), owner);
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)h.x, owner), b1 = (uint32_t)__builtin_amdgcn_readlane((int)h.y, owner),
+                   b2 = (uint32_t)__builtin_amdgcn_readlane((int)h.z, owner);
+    uint32_t r = rank - before, d = 0;
+    if (r >= b0) { r -= b0; d = 1; if (r >= b1) { r -= b1; d = 2; if (r >= b2) { r -= b2; d = 3; } } }
+    digit = 4u * (uint32_t)owner + d;
+    rank_in_bin = r;
+}
+
+// Exact element of 0-based rank `want` in list[0..n), by `team` consecutive threads (a multiple of 4) starting at
+// local index t: four lanes share one element e, each counts a quarter of the list (all lanes of a quad read the
+// same LDS words: broadcast), the quad adds up over DPP.  k is the answer iff #(x < k) <= want < #(x <= k); ties need
+// no order, every thread that finds it writes the same key.
+__device__ __forceinline__ void rank_pick(const uint32_t* list, uint32_t n, uint32_t want, uint32_t t, uint32_t team, uint32_t* result) {
+    const uint32_t part = t & 3u, quarter = (n + 3u) / 4u;
+    const uint32_t u_begin = part * quarter, u_end = min(u_begin + quarter, n);
+    for (uint32_t e = t >> 2; e < n; e += team >> 2) {
+        const uint32_t k = list[e];
+        uint32_t lt = 0, le = 0;
+#pragma unroll 4
+        for (uint32_t u = u_begin; u < u_end; ++u) {
+            const uint32_t x = list[u];
+            lt += x < k ? 1u : 0u;
+            le += x <= k ? 1u : 0u;
+        }
+        lt += dpp_move<0xB1, 0xF>(0u, lt);      // quad_perm [1,0,3,2]
+        le += dpp_move<0xB1, 0xF>(0u, le);
+        lt += dpp_move<0x4E, 0xF>(0u, lt);      // quad_perm [2,3,0,1]
+        le += dpp_move<0x4E, 0xF>(0u, le);
+        if (lt <= want && want < le) *result = k;
+    }
+}
+
 // Bracket-relative bin (0..255) of a key, linear in the float VALUE the key stands for (key-linear bins would
 // crowd: float keys spend one binade per exponent) and monotone in the key.  Values beyond the range
 // (open brackets) go to the end bins; a degenerate range gets scale 0 (everything in bin 0 -> radix paths).
@@ -410,20 +456,43 @@ __device__ __forceinline__ double bin_scale_for(uint32_t lo, uint32_t hi) {
     return (span > 0.0 && span < 1e300) ? 256.0 / span : 0.0;
 }
 
-// LDS scratch of a per-tile stage (one workgroup).
-struct TileScratch {
-    uint32_t keys[2][kSample];            // keys of the sample: one set for the angle, two for the concentrations
-    uint32_t hist[2][256];
-    uint32_t list[4][kShortList];
+// LDS scratch of a per-tile stage (one workgroup).  The sample (_s) and candidate (_c) selections have their own
+// histograms, lists and counters, so one reset at the top of the kernel serves both.
+struct alignas(16) TileScratch {
+    uint32_t keys[2][kSample];            // keys of the sample (read back only by the crowded-bin fallback)
+    uint32_t hist_s[2][256];              // sample: one histogram per key set
+    uint32_t hist_c[2][256];              // candidates: one histogram per slot of the pair
+    uint32_t radix_hist[256];
+    uint32_t list_s[4][kShortList];
+    uint32_t list_c[2][kShortList];
     double mom[kMoments];
     double stage[32][kMoments];
-    unsigned long long rank_in_bin[4], radix_rank, n_sel;
-    uint32_t bin[4], count[4], result[4];
+    unsigned long long radix_rank, n_sel;
+    uint32_t bin_s[4], rank_in_bin_s[4], count_s[4], result_s[4];
+    uint32_t bin_c[2], rank_in_bin_c[2], count_c[2], result_c[2];
     uint32_t range_lo[2], range_hi[2], radix_digit;
-    int valid;
+    uint32_t valid;
     float coef[6];
     int flag;
 };
+
+__device__ __forceinline__ void reset_scratch(TileScratch* sh) {
+    for (int t = threadIdx.x; t < 512; t += blockDim.x) {
+        (&sh->hist_s[0][0])[t] = 0;
+        (&sh->hist_c[0][0])[t] = 0;
+    }
+    if (threadIdx.x < 4) {
+        sh->count_s[threadIdx.x] = 0;
+        sh->result_s[threadIdx.x] = 0;
+    }
+    if (threadIdx.x < 2) {
+        sh->count_c[threadIdx.x] = 0;
+        sh->result_c[threadIdx.x] = 0;
+        sh->range_lo[threadIdx.x] = 0xFFFFFFFFu;
+        sh->range_hi[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 0) sh->valid = 0;
+}
 
 // Exact rank-th smallest (0-based) of the valid keys produced by key_at(i), i in [0,count): four 8-bit radix
 // rounds, keys recomputed/re-read in every round.  Slow path, whole workgroup.
@@ -433,17 +502,17 @@ __device__ uint32_t radix_select_stream(unsigned long long count, unsigned long 
     __syncthreads();
     if (threadIdx.x == 0) sh->radix_rank = rank;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int t = threadIdx.x; t < 256; t += blockDim.x) sh->hist[0][t] = 0;
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) sh->radix_hist[t] = 0;
         __syncthreads();
         for (unsigned long long i = threadIdx.x; i < count; i += blockDim.x) {
             uint32_t k;
-            if (key_at(i, k) && ((k ^ prefix) & mask) == 0) atomicAdd(&sh->hist[0][(k >> shift) & 255u], 1u);
+            if (key_at(i, k) && ((k ^ prefix) & mask) == 0) atomicAdd(&sh->radix_hist[(k >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (threadIdx.x < kWave) {
             uint32_t d;
             unsigned long long rb;
-            scan_pick(sh->hist[0], sh->radix_rank, d, rb);
+            scan_pick(sh->radix_hist, sh->radix_rank, d, rb);
             if (lane_id() == 0) {
                 sh->radix_digit = d;
                 sh->radix_rank = rb;
@@ -457,59 +526,62 @@ __device__ uint32_t radix_select_stream(unsigned long long count, unsigned long 
     return prefix;
 }
 
-// Two brackets from the sample keys in sh->keys (invalid entries are 0xFFFFFFFF).  n_sets == 1: both brackets
-// (wanted ranks k0[0], k0[1]) are taken in key set 0 (the two angle percentiles); n_sets == 2: bracket s is taken in
-// key set s (the two concentrations).  Two levels: one 256-bin value-linear histogram per key set over its
-// [min,max], one wave per wanted sample rank picks its bin, the keys of that bin are gathered and the exact
-// element found by rank counting (a crowded bin falls back to radix rounds).  Outputs per bracket: the bracket
-// keys and the (origin, scale) of the bracket-relative bins used for the candidates.
-__device__ void sample_brackets(TileScratch* sh, int n_sets, unsigned long long n_total, const unsigned long long (&k0)[2], uint32_t (&lo)[2], uint32_t (&hi)[2],
-                                double (&bin_origin)[2], double (&bin_scale)[2]) {
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        sh->range_lo[threadIdx.x] = 0xFFFFFFFFu;
-        sh->range_hi[threadIdx.x] = 0u;
-    }
-    if (threadIdx.x == 0) sh->valid = 0;
-    if (threadIdx.x < 4) sh->count[threadIdx.x] = 0;
-    for (int t = threadIdx.x; t < 512; t += blockDim.x) (&sh->hist[0][0])[t] = 0;
-    __syncthreads();
-    uint32_t valid = 0;
-    for (int set = 0; set < n_sets; ++set) {
-        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-        for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
-            const uint32_t k = sh->keys[set][j];
-            if (k != 0xFFFFFFFFu) {
-                mn = min(mn, k);
-                mx = max(mx, k);
-                if (set == 0) ++valid;
+// Two brackets from the sample keys a per-tile stage holds in registers (key[set][i] belongs to sample
+// i*kGroupThreads + threadIdx.x; invalid entries are 0xFFFFFFFF; the caller also left them in sh->keys).
+// kSets == 1: both brackets (wanted ranks k0[0], k0[1]) are taken in key set 0 (the two angle percentiles);
+// kSets == 2: bracket s is taken in key set s (the two concentrations).  Two levels: a 256-bin value-linear
+// histogram per key set over its [min,max], one wave per wanted sample rank picks its bin, the keys of that bin
+// are listed and the exact element found by rank counting (a crowded bin falls back to radix rounds).  Outputs
+// per bracket: the bracket keys and the (origin, scale) of the bracket-relative bins used for the candidates.
+// Needs reset_scratch() and a barrier before it; five barriers inside.
+template <int kSets>
+__device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kKeys], unsigned long long n_total, const unsigned long long (&k0)[2], uint32_t (&lo)[2],
+                                uint32_t (&hi)[2], double (&bin_origin)[2], double (&bin_scale)[2]) {
+    const uint32_t lane = lane_id();
+    {
+        uint32_t valid = 0;
+#pragma unroll
+        for (int set = 0; set < kSets; ++set) {
+            uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+            for (int i = 0; i < kKeys; ++i) {
+                const uint32_t k = key[set][i];
+                if (k != 0xFFFFFFFFu) {
+                    mn = min(mn, k);
+                    mx = max(mx, k);
+                    if (set == 0) ++valid;
+                }
+            }
+            mn = wave_min_u32(mn);
+            mx = wave_max_u32(mx);
+            if (lane == 0 && mn != 0xFFFFFFFFu) {
+                atomicMin(&sh->range_lo[set], mn);
+                atomicMax(&sh->range_hi[set], mx);
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mn = min(mn, (uint32_t)__shfl_down(mn, off, kWave));
-            mx = max(mx, (uint32_t)__shfl_down(mx, off, kWave));
-        }
-        if (lane_id() == 0) {
-            atomicMin(&sh->range_lo[set], mn);
-            atomicMax(&sh->range_hi[set], mx);
-        }
+        valid = wave_total_u32(valid);      // both concentration sets hold every sample pixel, so set 0's count serves both
+        if (lane == 0 && valid) atomicAdd(&sh->valid, valid);
     }
-    valid = wave_sum_u32(valid);
-    if (lane_id() == 0 && valid) atomicAdd(&sh->valid, (int)valid);
     __syncthreads();
-    const int m_valid = sh->valid;     // both concentration sets hold every sample pixel, so set 0's count serves both
-    uint32_t set_lo[2], set_hi[2];
-    double origin[2], scale[2];
+    const int m_valid = (int)sh->valid;
+    if (m_valid == 0) {      // nothing selected in the sample (uniform): open brackets, the count check sends the stage to the slow path
 #pragma unroll
-    for (int set = 0; set < 2; ++set) {
-        set_lo[set] = sh->range_lo[set < n_sets ? set : 0];
-        set_hi[set] = sh->range_hi[set < n_sets ? set : 0];
-        origin[set] = bin_origin_for(set_lo[set]);
-        scale[set] = bin_scale_for(set_lo[set], set_hi[set]);
+        for (int s = 0; s < 2; ++s) {
+            lo[s] = 0u;
+            hi[s] = 0xFFFFFFFFu;
+            bin_origin[s] = 0.0;
+            bin_scale[s] = 0.0;
+        }
+        return;
     }
-    bool want[4];
-    unsigned long long rank[4];
+    double origin[kSets], scale[kSets];
+#pragma unroll
+    for (int set = 0; set < kSets; ++set) {
+        const uint32_t set_lo = sh->range_lo[set], set_hi = sh->range_hi[set];
+        origin[set] = bin_origin_for(set_lo);
+        scale[set] = bin_scale_for(set_lo, set_hi);
+    }
+    uint32_t rank[4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         long long lo_r, hi_r;
@@ -517,94 +589,75 @@ __device__ void sample_brackets(TileScratch* sh, int n_sets, unsigned long long 
         // a bracket rank beyond the sample is clamped to the sample's extreme: the bracket stays closed (an open side
         // would gather the whole tail, ~1 % of the tile); the wanted element lying beyond all 4096 samples is a
         // 1e-18 event and, like every bracket miss, is caught by the count check and repaired by the slow path
-        want[2 * s] = want[2 * s + 1] = m_valid > 0;
-        rank[2 * s] = (unsigned long long)min(max(lo_r, 0ll), (long long)m_valid - 1);
-        rank[2 * s + 1] = (unsigned long long)min(max(hi_r, 0ll), (long long)m_valid - 1);
+        rank[2 * s] = (uint32_t)min(max(lo_r, 0ll), (long long)m_valid - 1);
+        rank[2 * s + 1] = (uint32_t)min(max(hi_r, 0ll), (long long)m_valid - 1);
     }
-    for (int set = 0; set < n_sets; ++set)
-        for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
-            const uint32_t k = sh->keys[set][j];
-            if (k != 0xFFFFFFFFu) atomicAdd(&sh->hist[set][bin_of(k, origin[set], scale[set])], 1u);
+    uint32_t bin[kSets][kKeys];
+#pragma unroll
+    for (int set = 0; set < kSets; ++set)
+#pragma unroll
+        for (int i = 0; i < kKeys; ++i) {
+            const uint32_t k = key[set][i];
+            bin[set][i] = 0xFFFFFFFFu;
+            if (k != 0xFFFFFFFFu) {
+                bin[set][i] = bin_of(k, origin[set], scale[set]);
+                atomicAdd(&sh->hist_s[set][bin[set][i]], 1u);
+            }
         }
     __syncthreads();
     const int wave = threadIdx.x / kWave;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (wave == q && want[q]) {
-            uint32_t b;
-            unsigned long long rb;
-            scan_pick(sh->hist[n_sets == 2 ? (q >> 1) : 0], rank[q], b, rb);
-            if (lane_id() == 0) {
-                sh->bin[q] = b;
-                sh->rank_in_bin[q] = rb;
-            }
+    if (wave < 4) {
+        uint32_t b, rb;
+        scan_pick32(sh->hist_s[kSets == 2 ? (wave >> 1) : 0], rank[wave], b, rb);
+        if (lane == 0) {
+            sh->bin_s[wave] = b;
+            sh->rank_in_bin_s[wave] = rb;
         }
     }
     __syncthreads();
-    for (int set = 0; set < n_sets; ++set)
-        for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
-            const uint32_t k = sh->keys[set][j];
-            if (k == 0xFFFFFFFFu) continue;
-            const uint32_t b = bin_of(k, origin[set], scale[set]);
+    {
+        uint32_t picked[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int q_set = n_sets == 2 ? (q >> 1) : 0;
-                if (q_set == set && want[q] && b == sh->bin[q]) {
-                    const uint32_t at = atomicAdd(&sh->count[q], 1u);
-                    if (at < (uint32_t)kShortList) sh->list[q][at] = k;
+        for (int q = 0; q < 4; ++q) picked[q] = sh->bin_s[q];
+#pragma unroll
+        for (int set = 0; set < kSets; ++set)
+#pragma unroll
+            for (int i = 0; i < kKeys; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int q_set = kSets == 2 ? (q >> 1) : 0;
+                    if (q_set == set && bin[set][i] == picked[q]) {
+                        const uint32_t at = atomicAdd(&sh->count_s[q], 1u);
+                        if (at < (uint32_t)kShortList) sh->list_s[q][at] = key[set][i];
+                    }
                 }
-            }
-        }
+    }
     __syncthreads();
-    uint32_t res[4] = {0, 0, 0, 0};
+    uint32_t res[4];
     bool crowded = false;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (want[q] && sh->count[q] > (uint32_t)kShortList) crowded = true;
+    for (int q = 0; q < 4; ++q) crowded = crowded || sh->count_s[q] > (uint32_t)kShortList;
     if (!crowded) {
-        // the four short lists are ranked side by side: a quarter of the waves each
-        const int n_waves = blockDim.x / kWave, per = n_waves >= 4 ? n_waves / 4 : 1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (!want[q]) continue;
-            const int first = n_waves >= 4 ? q * per : 0;
-            if (wave >= first && wave < first + per) {
-                const uint32_t n = sh->count[q], lane = lane_id();
-                for (uint32_t i = (uint32_t)(wave - first); i < n; i += (uint32_t)per) {
-                    const uint32_t k = sh->list[q][i];
-                    uint32_t c = 0;
-                    for (uint32_t t = lane; t < n; t += kWave) {
-                        const uint32_t x = sh->list[q][t];
-                        c += (x < k || (x == k && t < i)) ? 1u : 0u;
-                    }
-                    c = wave_sum_u32(c);
-                    if (lane == 0 && c == sh->rank_in_bin[q]) sh->result[q] = k;
-                }
-            }
-        }
+        // the four short lists are ranked side by side, a quarter of the workgroup each
+        const uint32_t per = blockDim.x / 4, q = threadIdx.x / per;
+        rank_pick(sh->list_s[q], sh->count_s[q], sh->rank_in_bin_s[q], threadIdx.x - q * per, per, &sh->result_s[q]);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) res[q] = sh->result[q];
+        for (int q2 = 0; q2 < 4; ++q2) res[q2] = sh->result_s[q2];
     } else {    // a crowded bin (uniform decision: the counts live in LDS): radix rounds over the sample
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (!want[q]) continue;
-            const uint32_t* keys = sh->keys[n_sets == 2 ? (q >> 1) : 0];
-            res[q] = radix_select_stream((unsigned long long)kSample, rank[q], [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return k != 0xFFFFFFFFu; }, sh);
+            const uint32_t* keys = sh->keys[kSets == 2 ? (q >> 1) : 0];
+            res[q] = radix_select_stream((unsigned long long)kSample, (unsigned long long)rank[q], [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return k != 0xFFFFFFFFu; }, sh);
         }
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int set = n_sets == 2 ? s : 0;
-        lo[s] = want[2 * s] ? res[2 * s] : 0u;
-        hi[s] = want[2 * s + 1] ? res[2 * s + 1] : 0xFFFFFFFFu;
-        // candidate bins span the bracket; an open side is bounded by the sample's extreme (the few keys beyond it
-        // fall into the end bin)
-        const uint32_t range_lo = want[2 * s] ? res[2 * s] : set_lo[set], range_hi = want[2 * s + 1] ? res[2 * s + 1] : set_hi[set];
-        bin_origin[s] = bin_origin_for(range_lo);
-        bin_scale[s] = m_valid > 0 ? bin_scale_for(range_lo, range_hi) : 0.0;
+        lo[s] = res[2 * s];
+        hi[s] = res[2 * s + 1];
+        bin_origin[s] = bin_origin_for(lo[s]);      // candidate bins span the bracket
+        bin_scale[s] = bin_scale_for(lo[s], hi[s]);
     }
-    __syncthreads();
 }
 
 // Pixel walker of one group: tile-local for transform, all tiles for the pooled fit.
@@ -887,9 +940,24 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
 // ------------------------------------------------------------------------------------------------
 // per-tile stage A ("plane"): moments -> covariance -> plane vectors; angle brackets from the sample
 // ------------------------------------------------------------------------------------------------
+// Optical density of the sample pixels this thread owns (written by S1).
+__device__ __forceinline__ void load_sample(const Workspace& ws, int group, int m, float (&od)[kKeys][3]) {
+    const float* sample = ws.sample_od + (size_t)group * 3 * kSample;
+#pragma unroll
+    for (int i = 0; i < kKeys; ++i) {
+        const int j = i * kGroupThreads + (int)threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) od[i][c] = j < m ? get(&sample[c * kSample + j]) : 0.0f;
+    }
+}
+
 __device__ void plane_stage(const Geometry& g, const Workspace& ws, int group, int allow_fallback, TileScratch* sh) {
     GroupState& st = ws.state[group];
     SX_STAMP(st, 0);
+    reset_scratch(sh);
+    // the sample is fetched first: its latency hides behind the moments and the eigen-decomposition
+    float sod[kKeys][3];
+    load_sample(ws, group, g.sample_count, sod);
     {
         // fixed-order (deterministic) sum of the work items' partial moments: lanes fetch them in parallel, one
         // thread per moment adds them in index order
@@ -942,22 +1010,21 @@ __device__ void plane_stage(const Geometry& g, const Workspace& ws, int group, i
     float v[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) v[i] = sh->coef[i];
-    // angle keys of the selected sample pixels (their OD was written by S1)
-    const float* sample = ws.sample_od + (size_t)group * 3 * kSample;
-    const int m = g.sample_count;
-    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (j < m) {
-            const float od[3] = {get(&sample[j]), get(&sample[kSample + j]), get(&sample[2 * kSample + j])};
-            if (od_selected(od, use_all)) key = angle_key(od, v);
-        }
-        sh->keys[0][j] = key;
+    // angle keys of the selected sample pixels
+    uint32_t key[1][kKeys];
+#pragma unroll
+    for (int i = 0; i < kKeys; ++i) {
+        const int j = i * kGroupThreads + (int)threadIdx.x;
+        uint32_t k = 0xFFFFFFFFu;
+        if (j < g.sample_count && od_selected(sod[i], use_all)) k = angle_key(sod[i], v);
+        key[0][i] = k;
+        sh->keys[0][j] = k;
     }
     SX_STAMP(st, 3);
     const unsigned long long k0[2] = {nearest_rank_index(1.0, n_sel), nearest_rank_index(99.0, n_sel)};   // alpha = 1 (torch_backend.py:421-422)
     uint32_t lo[2], hi[2];
     double origin[2], scale[2];
-    sample_brackets(sh, 1, n_sel, k0, lo, hi, origin, scale);
+    sample_brackets<1>(sh, key, n_sel, k0, lo, hi, origin, scale);
     SX_STAMP(st, 4);
     if (threadIdx.x == 0) {
         StageRecord* rec = &st.rec[0];
@@ -1001,116 +1068,137 @@ __device__ uint32_t select_whole_group(const T* __restrict__ images, const Geome
                                sh);
 }
 
-// Sum the work items' bracket-relative histograms (fixed order), one wave per slot picks the bin holding the
-// wanted rank, the candidates of that bin (~n/256 keys) are gathered and rank-counted.  Anything unusual --
-// bracket missed or overflowed, a crowded bin -- goes to the radix paths (over the candidates, or recomputing
-// every key of the group from the pixels).
-template <typename T>
-__device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, const float* coef, bool use_all,
-                             uint32_t (&key_out)[2], TileScratch* sh) {
-    GroupState& st = ws.state[group];
-    const StageRecord* rec = &st.rec[first_slot ? 1 : 0];
-    bool ok[2];
-    uint32_t ncand[2];
+// What resolve_pair() needs from memory, fetched at the top of the kernel in one batch (one memory latency for
+// the whole stage instead of one per step): the counters of the two slots, this thread's share of the work items'
+// histograms and the first 8192 candidates of each slot (loaded before ncand is known: the buffer is always at
+// least kMinCap long, entries beyond ncand are ignored later).
+struct PairPrefetch {
+    uint32_t ncand[2], below[2];
+    unsigned long long rank[2];
     double origin[2], scale[2];
-    unsigned long long want_in[2], want_all[2];
+    uint32_t hist[kPrefetchHist];
+    uint32_t cand[2][kPrefetchCand];
+};
+
+__device__ __forceinline__ void prefetch_pair(PairPrefetch& pf, const Geometry& g, const Workspace& ws, int group, int first_slot) {
+    const GroupState& st = ws.state[group];
+    const StageRecord* rec = &st.rec[first_slot ? 1 : 0];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int slot = first_slot + j;
-        ncand[j] = get(&st.ncand[slot]);
-        const unsigned long long below = get(&st.below[slot]);
-        want_all[j] = get(&st.rank[slot]);
-        ok[j] = ncand[j] <= g.cap && want_all[j] >= below && want_all[j] - below < ncand[j];
-        want_in[j] = ok[j] ? want_all[j] - below : 0ull;
-        origin[j] = get(&rec->bin_origin[j]);
-        scale[j] = get(&rec->bin_scale[j]);
+        pf.ncand[j] = get(&st.ncand[slot]);
+        pf.below[j] = get(&st.below[slot]);
+        pf.rank[j] = get(&st.rank[slot]);
+        pf.origin[j] = get(&rec->bin_origin[j]);
+        pf.scale[j] = get(&rec->bin_scale[j]);
     }
-    __syncthreads();
     const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
     const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
-    if (threadIdx.x < 2) sh->count[threadIdx.x] = 0;
-    for (int t = threadIdx.x; t < 512; t += blockDim.x) {     // thread owns bin t%256 of slot t/256
-        const uint32_t* src = ws.block_hist + first * 512 + t;
+    const uint32_t* src = ws.block_hist + first * 512 + (threadIdx.x & 511);     // thread owns bin t%256 of slot (t/256)%2 ...
+    const int half = (int)threadIdx.x >> 9;                                        // ... for every second work item
+#pragma unroll
+    for (int u = 0; u < kPrefetchHist; ++u) {
+        const int64_t blk = half + 2 * u;
+        pf.hist[u] = blk < nblk ? get(&src[blk * 512]) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t* cand = ws.cand + ((size_t)group * kSlots + first_slot + j) * g.cap;
+#pragma unroll
+        for (int u = 0; u < kPrefetchCand; ++u) pf.cand[j][u] = get(&cand[u * kGroupThreads + threadIdx.x]);
+    }
+}
+
+// Exact order statistics of the two slots of a stage from what the streaming stage left behind: the work items'
+// bracket-relative histograms are summed (integers: any order), one wave per slot picks the bin holding the wanted
+// rank, the candidates of that bin (~n/256 keys) are listed and rank-counted.  Anything unusual -- bracket missed
+// or overflowed, a crowded bin -- goes to the radix paths (over the candidates, or recomputing every key of the
+// group from the pixels).  Needs reset_scratch() before it.
+template <typename T>
+__device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, const float* coef, bool use_all,
+                             const PairPrefetch& pf, uint32_t (&key_out)[2], TileScratch* sh) {
+    GroupState& st = ws.state[group];
+    bool ok[2];
+    uint32_t want_in[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ok[j] = pf.ncand[j] <= g.cap && pf.rank[j] >= pf.below[j] && pf.rank[j] - pf.below[j] < pf.ncand[j];
+        want_in[j] = ok[j] ? (uint32_t)(pf.rank[j] - pf.below[j]) : 0u;
+    }
+    const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
+    const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
+    __syncthreads();      // the scratch reset is visible
+    {
+        const uint32_t* src = ws.block_hist + first * 512 + (threadIdx.x & 511);
         uint32_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < kPrefetchHist; ++u) sum += pf.hist[u];
 #pragma unroll 8
-        for (int64_t b = 0; b < nblk; ++b) sum += get(&src[b * 512]);
-        (&sh->hist[0][0])[t] = sum;
+        for (int64_t blk = ((int)threadIdx.x >> 9) + 2 * kPrefetchHist; blk < nblk; blk += 2) sum += get(&src[blk * 512]);
+        if (sum) atomicAdd(&(&sh->hist_c[0][0])[threadIdx.x & 511], sum);
     }
     __syncthreads();
     const int wave = threadIdx.x / kWave;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (wave == j && ok[j]) {
-            uint32_t b;
-            unsigned long long rb;
-            scan_pick(sh->hist[j], want_in[j], b, rb);
-            if (lane_id() == 0) {
-                sh->bin[j] = b;
-                sh->rank_in_bin[j] = rb;
-            }
+    if (wave < 2 && ok[wave]) {
+        uint32_t b, rb;
+        scan_pick32(sh->hist_c[wave], want_in[wave], b, rb);
+        if (lane_id() == 0) {
+            sh->bin_c[wave] = b;
+            sh->rank_in_bin_c[wave] = rb;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (!ok[j]) continue;
+        const uint32_t b = sh->bin_c[j], n = pf.ncand[j];
+#pragma unroll
+        for (int u = 0; u < kPrefetchCand; ++u) {
+            const uint32_t idx = u * kGroupThreads + threadIdx.x, k = pf.cand[j][u];
+            if (idx < n && bin_of(k, pf.origin[j], pf.scale[j]) == b) {
+                const uint32_t at = atomicAdd(&sh->count_c[j], 1u);
+                if (at < (uint32_t)kShortList) sh->list_c[j][at] = k;
+            }
+        }
+        // big tiles / pooled groups: the rest of the candidates, eight independent loads in flight
         const uint32_t* cand = ws.cand + ((size_t)group * kSlots + first_slot + j) * g.cap;
-        const uint32_t b = sh->bin[j];
-        for (uint32_t base = threadIdx.x; base < ncand[j]; base += blockDim.x * 8) {
+        for (uint32_t base = kPrefetchCand * kGroupThreads + threadIdx.x; base < n; base += kGroupThreads * 8) {
             uint32_t k[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {          // eight independent loads in flight
-                const uint32_t idx = base + u * blockDim.x;
-                k[u] = idx < ncand[j] ? get(&cand[idx]) : 0u;
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t idx = base + u * kGroupThreads;
+                k[u] = idx < n ? get(&cand[idx]) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const uint32_t idx = base + u * blockDim.x;
-                if (idx < ncand[j] && bin_of(k[u], origin[j], scale[j]) == b) {
-                    const uint32_t at = atomicAdd(&sh->count[j], 1u);
-                    if (at < (uint32_t)kShortList) sh->list[j][at] = k[u];
+                const uint32_t idx = base + u * kGroupThreads;
+                if (idx < n && bin_of(k[u], pf.origin[j], pf.scale[j]) == b) {
+                    const uint32_t at = atomicAdd(&sh->count_c[j], 1u);
+                    if (at < (uint32_t)kShortList) sh->list_c[j][at] = k[u];
                 }
             }
         }
     }
     __syncthreads();
-    {   // rank counting of the two short lists, half the waves each
-        const int n_waves = blockDim.x / kWave, half = n_waves >= 2 ? n_waves / 2 : 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (!(ok[j] && sh->count[j] <= (uint32_t)kShortList)) continue;
-            const int first = n_waves >= 2 ? j * half : 0;
-            if (wave >= first && wave < first + half) {
-                const uint32_t n = sh->count[j], lane = lane_id();
-                for (uint32_t i = (uint32_t)(wave - first); i < n; i += (uint32_t)half) {
-                    const uint32_t k = sh->list[j][i];
-                    uint32_t c = 0;
-                    for (uint32_t t = lane; t < n; t += kWave) {
-                        const uint32_t x = sh->list[j][t];
-                        c += (x < k || (x == k && t < i)) ? 1u : 0u;
-                    }
-                    c = wave_sum_u32(c);
-                    if (lane == 0 && c == sh->rank_in_bin[j]) sh->result[j] = k;
-                }
-            }
-        }
+    {   // rank counting of the two short lists side by side, half the workgroup each
+        const uint32_t per = blockDim.x / 2, j = threadIdx.x / per;
+        if (ok[j] && sh->count_c[j] <= (uint32_t)kShortList) rank_pick(sh->list_c[j], sh->count_c[j], sh->rank_in_bin_c[j], threadIdx.x - j * per, per, &sh->result_c[j]);
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int slot = first_slot + j;
-        if (ok[j] && sh->count[j] <= (uint32_t)kShortList) {
-            key_out[j] = sh->result[j];        // ranked above, both lists side by side
+        if (ok[j] && sh->count_c[j] <= (uint32_t)kShortList) {
+            key_out[j] = sh->result_c[j];
         } else if (ok[j]) {      // crowded bin: radix rounds over the candidates
             const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * g.cap;
             if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
-            key_out[j] = radix_select_stream((unsigned long long)ncand[j], want_in[j], [cand](unsigned long long i, uint32_t& k) { k = get(&cand[i]); return true; }, sh);
+            key_out[j] = radix_select_stream((unsigned long long)pf.ncand[j], (unsigned long long)want_in[j], [cand](unsigned long long i, uint32_t& k) { k = get(&cand[i]); return true; }, sh);
         } else {                 // the bracket did not hold: recompute every key of the group
             if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << slot);
-            key_out[j] = select_whole_group<T>(images, g, group, slot, want_all[j], coef, use_all, sh);
+            key_out[j] = select_whole_group<T>(images, g, group, slot, pf.rank[j], coef, use_all, sh);
         }
     }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1121,12 +1209,17 @@ __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, con
     GroupState& st = ws.state[group];
     const GroupPixels gp = group_pixels(g, group);
     SX_STAMP(st, 6);
+    reset_scratch(sh);
+    PairPrefetch pf;
+    prefetch_pair(pf, g, ws, group, 0);
+    float sod[kKeys][3];
+    load_sample(ws, group, g.sample_count, sod);
     float vecs[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) vecs[i] = get(&st.rec[0].coef[i]);
     const bool use_all = get(&st.rec[0].use_all) != 0;
     uint32_t phi_key[2];
-    resolve_pair<T>(images, g, ws, group, 0, vecs, use_all, phi_key, sh);
+    resolve_pair<T>(images, g, ws, group, 0, vecs, use_all, pf, phi_key, sh);
     SX_STAMP(st, 7);
     if (threadIdx.x == 0) {
         const float phi_lo = angle_from_key(phi_key[0]), phi_hi = angle_from_key(phi_key[1]);
@@ -1140,37 +1233,37 @@ __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, con
         }
         put(&st.phi[0], phi_lo);
         put(&st.phi[1], phi_hi);
-        put(&st.ncand_seen[0], get(&st.ncand[0]));
-        put(&st.ncand_seen[1], get(&st.ncand[1]));
+        put(&st.ncand_seen[0], pf.ncand[0]);
+        put(&st.ncand_seen[1], pf.ncand[1]);
     }
     __syncthreads();
     SX_STAMP(st, 8);
-    // concentration brackets from the same strided sample (every pixel takes part: torch_backend.py:442-448),
-    // one key set at a time
+    // concentration brackets from the same sample (every pixel takes part: torch_backend.py:442-448)
     float pinv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) pinv[i] = sh->coef[i];
-    const float* sample = ws.sample_od + (size_t)group * 3 * kSample;
-    const int m = g.sample_count;
     const unsigned long long n_all = (unsigned long long)gp.count;
     const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
-    uint32_t lo[2], hi[2];
-    double origin[2], scale[2];
-    __syncthreads();
-    for (int j = threadIdx.x; j < kSample; j += blockDim.x) {
+    uint32_t key[2][kKeys];
+#pragma unroll
+    for (int i = 0; i < kKeys; ++i) {
+        const int j = i * kGroupThreads + (int)threadIdx.x;
         uint32_t ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
-        if (j < m) {
-            const float od[3] = {get(&sample[j]), get(&sample[kSample + j]), get(&sample[2 * kSample + j])};
+        if (j < g.sample_count) {
             float c0, c1;
-            concentration(od, pinv, c0, c1);
+            concentration(sod[i], pinv, c0, c1);
             ka = float_key(c0);
             kb = float_key(c1);
         }
+        key[0][i] = ka;
+        key[1][i] = kb;
         sh->keys[0][j] = ka;
         sh->keys[1][j] = kb;
     }
     const unsigned long long k0[2] = {k99, k99};
-    sample_brackets(sh, 2, n_all, k0, lo, hi, origin, scale);
+    uint32_t lo[2], hi[2];
+    double origin[2], scale[2];
+    sample_brackets<2>(sh, key, n_all, k0, lo, hi, origin, scale);
     SX_STAMP(st, 10);
     if (threadIdx.x == 0) {
         StageRecord* rec = &st.rec[1];
@@ -1196,18 +1289,21 @@ __device__ void scale_stage(const T* __restrict__ images, const Geometry& g, con
                             float* __restrict__ max_c_out, TileScratch* sh) {
     GroupState& st = ws.state[group];
     SX_STAMP(st, 12);
+    reset_scratch(sh);
+    PairPrefetch pf;
+    prefetch_pair(pf, g, ws, group, 2);
     float pinv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) pinv[i] = get(&st.rec[1].coef[i]);
     uint32_t c_key[2];
-    resolve_pair<T>(images, g, ws, group, 2, pinv, true, c_key, sh);
+    resolve_pair<T>(images, g, ws, group, 2, pinv, true, pf, c_key, sh);
     SX_STAMP(st, 13);
     if (threadIdx.x == 0) {
         const float m0 = key_float(c_key[0]), m1 = key_float(c_key[1]);
         put(&st.max_c[0], m0);
         put(&st.max_c[1], m1);
-        put(&st.ncand_seen[2], get(&st.ncand[2]));
-        put(&st.ncand_seen[3], get(&st.ncand[3]));
+        put(&st.ncand_seen[2], pf.ncand[2 - 2]);
+        put(&st.ncand_seen[3], pf.ncand[3 - 2]);
         StageRecord* rec = &st.rec[2];
 #pragma unroll
         for (int i = 0; i < 6; ++i) put(&rec->coef[i], pinv[i]);
@@ -1244,7 +1340,6 @@ __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __
     reconstruct_item<T, O, V, kUnit, kStreamThreads>(images, out, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, stain_matrix);
 }
 
-constexpr int kGroupThreads = 1024;    // per-tile stages as their own launch
 
 __global__ __launch_bounds__(kGroupThreads) void plane_kernel(Geometry g, Workspace ws, int allow_fallback) {
     __shared__ TileScratch sh;
