@@ -30,15 +30,16 @@ namespace macenko {
 
 constexpr int kSample = 4096;          // strided sample per tile
 constexpr int kMinCap = 32768;         // candidate keys per selection slot: at least this, 1/16 of the group's pixels for big groups
-constexpr int kChunk = 8192;           // pixels per work item (32 per lane of a 256-thread workgroup)
+constexpr int kChunk = 16384;          // pixels per work item (64 per lane of a 256-thread workgroup)
 template <typename T> struct PackOf { static constexpr int n = 16 / (int)sizeof(T); };   // pixels per 16-byte load: f32 4, bf16/f16 8, u8 16, f64 2
 constexpr int kSlots = 4;              // 0: phi@1  1: phi@99  2: C0@99  3: C1@99
-constexpr int kMoments = 20;           // [cnt,sx,sy,sz,xx,xy,xz,yy,yz,zz] masked, then all pixels
+constexpr int kMoments = 20;           // [cnt,sx,sy,sz,xx,xy,xz,yy,yz,zz] of the pixels kept by the OD filter, then of all pixels
+constexpr int kPartial = 10;           // what S1 accumulates per work item: the kept set only (the all-pixel set is a rare fallback)
 constexpr int kShortList = 512;        // keys of one histogram bin gathered for rank counting
 constexpr int kPhasePixels = 4096;     // pixels between two flushes of the LDS candidate queues
 constexpr int kGroupThreads = 1024;    // per-tile stages: one workgroup per group, as their own launch
 constexpr int kKeys = kSample / kGroupThreads;   // sample keys a thread of a per-tile stage holds in registers
-constexpr int kPrefetchHist = 16;      // work-item histograms a thread fetches up front (2 threads per bin: 32 work items = one 512x512 tile)
+constexpr int kPrefetchHist = 8;       // work-item histograms a thread fetches up front (2 threads per bin: 32 work items = one 512x512 tile)
 constexpr int kPrefetchCand = 8;       // candidates per slot a thread fetches up front (8192 per slot)
 static_assert(kKeys * kGroupThreads == kSample && kPrefetchCand * kGroupThreads <= kMinCap, "per-tile stage geometry");
 
@@ -89,7 +90,7 @@ struct Geometry {
 
 struct Workspace {
     GroupState* state;
-    double* partial;              // [n_tiles*blocks_per_tile][kMoments]
+    double* partial;              // [n_tiles*blocks_per_tile][kPartial]
     uint32_t* cand;               // [groups][kSlots][cap]
     uint32_t* block_hist;         // [n_tiles*blocks_per_tile][2][256] bracket-relative histograms of a stage's candidates
     float* sample_od;             // [groups][3][kSample] optical density of the strided sample
@@ -114,7 +115,7 @@ static size_t cand_words(int64_t n_tiles, int64_t pixels) {
 static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
     const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
     size_t total = align_up(sizeof(GroupState) * n, 256);
-    total += align_up(sizeof(double) * kMoments * b * n, 256);
+    total += align_up(sizeof(double) * kPartial * b * n, 256);
     total += align_up(sizeof(uint32_t) * cand_words(n_tiles, pixels), 256);
     total += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     total += align_up(sizeof(float) * 3 * kSample * n, 256);
@@ -128,7 +129,7 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     w.state = reinterpret_cast<GroupState*>(p);
     p += align_up(sizeof(GroupState) * n, 256);
     w.partial = reinterpret_cast<double*>(p);
-    p += align_up(sizeof(double) * kMoments * b * n, 256);
+    p += align_up(sizeof(double) * kPartial * b * n, 256);
     w.cand = reinterpret_cast<uint32_t*>(p);
     p += align_up(sizeof(uint32_t) * cand_words(n_tiles, pixels), 256);
     w.block_hist = reinterpret_cast<uint32_t*>(p);
@@ -466,7 +467,7 @@ struct alignas(16) TileScratch {
     uint32_t list_s[4][kShortList];
     uint32_t list_c[2][kShortList];
     double mom[kMoments];
-    double stage[32][kMoments];
+    double stage[64][kPartial];
     unsigned long long radix_rank, n_sel;
     uint32_t bin_s[4], rank_in_bin_s[4], count_s[4], result_s[4];
     uint32_t bin_c[2], rank_in_bin_c[2], count_c[2], result_c[2];
@@ -691,7 +692,7 @@ __device__ __forceinline__ uint32_t sample_offset(uint32_t j, int shift) { retur
 // streaming stage S1: raw moments of the OD vectors of one work item (+ the sample's OD on the way)
 // ------------------------------------------------------------------------------------------------
 template <int TPB> struct StatsScratch {
-    double red[TPB / kWave][kMoments];
+    double red[TPB / kWave][kPartial];
 };
 
 template <typename T, int V, int TPB>
@@ -702,62 +703,70 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     const int group = g.pooled ? 0 : (int)tile;
     float* sample_out = ws.sample_od + (size_t)group * 3 * kSample;
     const uint32_t group_offset = g.pooled ? (uint32_t)(tile * g.pixels) : 0u;      // position of this tile inside its group (< 2^32)
-    const uint32_t stride = (uint32_t)g.sample_stride, sample_count = (uint32_t)g.sample_count;
+    const uint32_t sample_count = (uint32_t)g.sample_count;
+    const uint32_t mask = (uint32_t)g.sample_stride - 1u;          // stride is a power of two
+    const int shift = 31 - __clz(g.sample_stride);
 
-    // products and the sums over this lane's 32 pixels in fp32, everything beyond in fp64: the fp32 rounding is
+    // products and the sums over 32 pixels of a lane in fp32, everything beyond in fp64: the fp32 rounding is
     // unbiased and averages out over the tile (~4e-9 on a covariance entry, measured against the fp64 covariance
     // in the tests), the cancellation in sum(xy) - sum(x)*mean(y) happens in fp64
-    float m[10], a[10];
+    constexpr int kShortRun = 32 / V > 0 ? 32 / V : 1;      // packs per fp32 run
+    double acc[kPartial];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) m[k] = a[k] = 0.0f;
-    const uint32_t mask = stride - 1u;          // stride is a power of two
-    const int shift = 31 - __clz((int)stride);
+    for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
 
-    for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
-        float u[3][V];
+    for (int64_t run = p_begin; run < p_end; run += (int64_t)TPB * V * kShortRun) {
+        float m[kPartial];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
-        const uint32_t gpos = group_offset + (uint32_t)p;      // position inside the group; samples sit at multiples of stride
+        for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
+        const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
+        for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
+            float u[3][V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float od[3];
+            for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
+            const uint32_t gpos = group_offset + (uint32_t)p;      // position inside the group
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
-            const float keep = od_selected(od, false) ? 1.0f : 0.0f;
-            const float pr[10] = {1.0f, od[0], od[1], od[2], od[0] * od[0], od[0] * od[1], od[0] * od[2], od[1] * od[1], od[1] * od[2], od[2] * od[2]};
+            for (int i = 0; i < V; ++i) {
+                float od[3];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                a[k] += pr[k];
-                m[k] = fmaf(keep, pr[k], m[k]);
-            }
-            // sample j sits in [j*stride, (j+1)*stride) at a hashed offset (a fixed offset would alias with the image
-            // width: stride 1024 on a 2048-wide tile samples two columns only)
-            const uint32_t pos = gpos + (uint32_t)i, j = pos >> shift;
-            if ((pos & mask) == sample_offset(j, shift) && j < sample_count) {
+                for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
+                const float keep = od_selected(od, false) ? 1.0f : 0.0f;
+                const float k0 = keep * od[0], k1 = keep * od[1], k2 = keep * od[2];
+                m[0] += keep;
+                m[1] += k0;
+                m[2] += k1;
+                m[3] += k2;
+                m[4] = fmaf(k0, od[0], m[4]);
+                m[5] = fmaf(k0, od[1], m[5]);
+                m[6] = fmaf(k0, od[2], m[6]);
+                m[7] = fmaf(k1, od[1], m[7]);
+                m[8] = fmaf(k1, od[2], m[8]);
+                m[9] = fmaf(k2, od[2], m[9]);
+                // sample j sits in [j*stride, (j+1)*stride) at a hashed offset (a fixed offset would alias with the image
+                // width: stride 1024 on a 2048-wide tile samples two columns only)
+                const uint32_t pos = gpos + (uint32_t)i, j = pos >> shift;
+                if ((pos & mask) == sample_offset(j, shift) && j < sample_count) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od[c]);
+                    for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od[c]);
+                }
             }
         }
-    }
-    double acc[kMoments];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        acc[k] = (double)m[k];
-        acc[10 + k] = (double)a[k];
+        for (int k = 0; k < kPartial; ++k) acc[k] += (double)m[k];
     }
 
     const int wave = threadIdx.x / kWave;
 #pragma unroll
-    for (int k = 0; k < kMoments; ++k) {
-        const double s = wave_sum(acc[k]);
-        if (lane_id() == 0) sh->red[wave][k] = s;
+    for (int k = 0; k < kPartial; ++k) {
+        const double s = wave_total_f64(acc[k]);       // fixed order; lane 63 holds the total
+        if (lane_id() == kWave - 1) sh->red[wave][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < kMoments) {
+    if (threadIdx.x < kPartial) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < TPB / kWave; ++w) s += sh->red[w][threadIdx.x];
-        put(&ws.partial[item * kMoments + threadIdx.x], s);
+        put(&ws.partial[item * kPartial + threadIdx.x], s);
     }
 }
 
@@ -765,16 +774,17 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
 // streaming stages S2 / S3: count keys below each bracket, gather + histogram the keys inside it
 //   kConc == false: slots 0,1 share the angle key of the selected pixels
 //   kConc == true : slots 2,3 use the two concentrations of every pixel
-// Candidates are queued in LDS; after every kPhasePixels pixels the queues (which therefore cannot overflow)
-// move to the tile's candidate buffers with ONE global atomic per slot.
+// Every wave works on its own: candidates are compacted (ballot + mbcnt, the running count lives in an SGPR)
+// into the wave's private LDS queue and moved to the tile's candidate buffer with ONE global atomic per slot when
+// the wave is done (or the queue is nearly full); there is no workgroup barrier inside the pixel loop, and the next
+// pack of pixels is already in flight while the current one is processed.
 // ------------------------------------------------------------------------------------------------
+constexpr int kQueue = 512;            // candidate keys a wave queues per slot before it must flush
+
 template <int TPB> struct BracketScratch {
-    static constexpr int kPhase = TPB * 4 > kPhasePixels ? TPB * 4 : kPhasePixels;   // at least one sweep of the workgroup
-    uint32_t count[2];
-    uint32_t base[2];
-    uint32_t keys[2][kPhase];
+    uint32_t keys[TPB / kWave][2][kQueue];
     uint32_t hist[2][256];        // bracket-relative histogram of everything this work item queued
-    uint32_t red[2][TPB / kWave];
+    uint32_t below[2];
 };
 
 __device__ __forceinline__ void load_record(const StageRecord* rec, StageRecord& out) {
@@ -791,90 +801,136 @@ __device__ __forceinline__ void load_record(const StageRecord* rec, StageRecord&
     out.use_all = get(&rec->use_all);
 }
 
+// Moves the n keys a wave queued for one slot to the group's candidate buffer and into the work item's histogram.
+__device__ __forceinline__ void flush_queue(const uint32_t* queue, uint32_t n, uint32_t* counter, uint32_t* dst, uint32_t cap, uint32_t* hist, double origin, double scale) {
+    if (n == 0) return;      // wave-uniform
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(counter, n);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    for (uint32_t i = lane_id(); i < n; i += kWave) {
+        const uint32_t key = queue[i];
+        if (base + i < cap) put(&dst[base + i], key);
+        atomicAdd(&hist[bin_of(key, origin, scale)], 1u);
+    }
+}
+
 template <typename T, int V, bool kConc, int TPB>
 __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, BracketScratch<TPB>* sh) {
-    constexpr int kPhase = BracketScratch<TPB>::kPhase;
     const int group = g.pooled ? 0 : (int)tile;
     GroupState& st = ws.state[group];
     constexpr int s0 = kConc ? 2 : 0;
     const int64_t p_begin = (int64_t)chunk_id * kChunk;
     const int64_t p_end = min(p_begin + (int64_t)kChunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    constexpr int kCheck = V < 4 ? V : 4;     // pixels between two looks at the queue fill
 
+    // The loop runs on the wave's base position, so all 64 lanes make the same trips (a lane past the end of the chunk
+    // carries `live == false`); the first pack is requested before anything else, the stage record right behind it.
+    int64_t base = p_begin + (int64_t)wave * kWave * V;
+    const int64_t mine = (int64_t)lane_id() * V;
+    float next[3][V];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < V; ++i) next[c][i] = 0.0f;
+    if (base + mine < p_end) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + base + mine, next[c]);
+    }
     StageRecord rec;
     load_record(&st.rec[kConc ? 1 : 0], rec);
-    if (threadIdx.x < 2) sh->count[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 512; i += TPB) (&sh->hist[0][0])[i] = 0;
+    if (threadIdx.x < 2) sh->below[threadIdx.x] = 0;
     __syncthreads();
 
     const bool use_all = kConc ? true : (rec.use_all != 0);
     const uint32_t lo_a = rec.lo[0], hi_a = rec.hi[0], lo_b = rec.lo[1], hi_b = rec.hi[1];
     uint32_t* cand_a = ws.cand + ((size_t)group * kSlots + s0) * g.cap;
     uint32_t* cand_b = cand_a + g.cap;
+    uint32_t* queue_a = sh->keys[wave][0];
+    uint32_t* queue_b = sh->keys[wave][1];
     uint32_t below_a = 0, below_b = 0;
+    uint32_t n_a = 0, n_b = 0;        // queued keys of this wave: uniform
 
-    for (int64_t phase_begin = p_begin; phase_begin < p_end; phase_begin += kPhase) {
-        const int64_t phase_end = min(phase_begin + (int64_t)kPhase, p_end);
-        for (int64_t p = phase_begin + (int64_t)threadIdx.x * V; p < phase_end; p += (int64_t)TPB * V) {
-            float u[3][V];
+    for (; base < p_end; base += (int64_t)TPB * V) {
+        const bool live = base + mine < p_end;
+        float u[3][V];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                float od[3];
+            for (int i = 0; i < V; ++i) u[c][i] = next[c][i];
+        const int64_t p_next = base + (int64_t)TPB * V + mine;
+        if (p_next < p_end) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
-                const bool valid = od_selected(od, use_all);
-                uint32_t key_a, key_b;
-                if constexpr (kConc) {
-                    float c0, c1;
-                    concentration(od, rec.coef, c0, c1);
-                    key_a = float_key(c0);
-                    key_b = float_key(c1);
-                } else {
-                    key_a = key_b = angle_key(od, rec.coef);
+            for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p_next, next[c]);
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float od[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
+            const bool valid = live && od_selected(od, use_all);
+            uint32_t key_a, key_b;
+            if constexpr (kConc) {
+                float c0, c1;
+                concentration(od, rec.coef, c0, c1);
+                key_a = float_key(c0);
+                key_b = float_key(c1);
+            } else {
+                key_a = key_b = angle_key(od, rec.coef);
+            }
+            below_a += (valid && key_a < lo_a) ? 1u : 0u;
+            below_b += (valid && key_b < lo_b) ? 1u : 0u;
+            const bool in_a = valid && key_a >= lo_a && key_a <= hi_a, in_b = valid && key_b >= lo_b && key_b <= hi_b;
+            const uint64_t m_a = __ballot(in_a), m_b = __ballot(in_b);
+            if (in_a) queue_a[n_a + rank_in_mask(m_a)] = key_a;
+            if (in_b) queue_b[n_b + rank_in_mask(m_b)] = key_b;
+            n_a += (uint32_t)__popcll(m_a);
+            n_b += (uint32_t)__popcll(m_b);
+            if ((i + 1) % kCheck == 0) {      // the next kCheck pixels add at most kCheck * 64 keys
+                if (n_a > (uint32_t)(kQueue - kCheck * kWave)) {
+                    flush_queue(queue_a, n_a, &st.ncand[s0], cand_a, g.cap, sh->hist[0], rec.bin_origin[0], rec.bin_scale[0]);
+                    n_a = 0;
                 }
-                below_a += (valid && key_a < lo_a) ? 1u : 0u;
-                below_b += (valid && key_b < lo_b) ? 1u : 0u;
-                if (valid && key_a >= lo_a && key_a <= hi_a) sh->keys[0][atomicAdd(&sh->count[0], 1u)] = key_a;
-                if (valid && key_b >= lo_b && key_b <= hi_b) sh->keys[1][atomicAdd(&sh->count[1], 1u)] = key_b;
+                if (n_b > (uint32_t)(kQueue - kCheck * kWave)) {
+                    flush_queue(queue_b, n_b, &st.ncand[s0 + 1], cand_b, g.cap, sh->hist[1], rec.bin_origin[1], rec.bin_scale[1]);
+                    n_b = 0;
+                }
             }
         }
-        __syncthreads();
-        if (threadIdx.x < 2) {
-            const uint32_t n_local = sh->count[threadIdx.x];
-            sh->base[threadIdx.x] = n_local ? atomicAdd(&st.ncand[s0 + threadIdx.x], n_local) : 0u;
+    }
+    {   // the wave's last flush: both reservations are requested before either is waited for
+        uint32_t base_a = 0, base_b = 0;
+        if (lane_id() == 0) {
+            if (n_a) base_a = atomicAdd(&st.ncand[s0], n_a);
+            if (n_b) base_b = atomicAdd(&st.ncand[s0 + 1], n_b);
         }
-        __syncthreads();
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            uint32_t* dst = which == 0 ? cand_a : cand_b;
-            const uint32_t n_local = sh->count[which], base = sh->base[which];
-            const double origin = rec.bin_origin[which], scale = rec.bin_scale[which];
-            for (uint32_t i = threadIdx.x; i < n_local; i += TPB) {
-                const uint32_t key = sh->keys[which][i];
-                if (base + i < g.cap) put(&dst[base + i], key);
-                atomicAdd(&sh->hist[which][bin_of(key, origin, scale)], 1u);
-            }
+        base_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_a);
+        base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_b);
+        for (uint32_t i = lane_id(); i < n_a; i += kWave) {
+            const uint32_t key = queue_a[i];
+            if (base_a + i < g.cap) put(&cand_a[base_a + i], key);
+            atomicAdd(&sh->hist[0][bin_of(key, rec.bin_origin[0], rec.bin_scale[0])], 1u);
         }
-        __syncthreads();
-        if (threadIdx.x < 2) sh->count[threadIdx.x] = 0;
-        __syncthreads();
+        for (uint32_t i = lane_id(); i < n_b; i += kWave) {
+            const uint32_t key = queue_b[i];
+            if (base_b + i < g.cap) put(&cand_b[base_b + i], key);
+            atomicAdd(&sh->hist[1][bin_of(key, rec.bin_origin[1], rec.bin_scale[1])], 1u);
+        }
     }
 
-    const uint32_t wa = wave_sum_u32(below_a), wb = wave_sum_u32(below_b);
+    const uint32_t wa = wave_total_u32(below_a), wb = wave_total_u32(below_b);
     if (lane_id() == 0) {
-        sh->red[0][threadIdx.x / kWave] = wa;
-        sh->red[1][threadIdx.x / kWave] = wb;
+        if (wa) atomicAdd(&sh->below[0], wa);
+        if (wb) atomicAdd(&sh->below[1], wb);
     }
     __syncthreads();
     if (threadIdx.x < 2) {
-        uint32_t sum = 0;
-#pragma unroll
-        for (int w = 0; w < TPB / kWave; ++w) sum += sh->red[threadIdx.x][w];
+        const uint32_t sum = sh->below[threadIdx.x];
         if (sum) atomicAdd(&st.below[s0 + threadIdx.x], sum);
     }
-    // the work item's histograms are stored -- not added -- so the per-tile stage can sum them in a fixed order
+    // the work item's histograms are stored -- not added -- so the per-tile stage reads them without a reset
     uint32_t* hist_out = ws.block_hist + (size_t)item * 512;
     for (int i = threadIdx.x; i < 512; i += TPB) put(&hist_out[i], (&sh->hist[0][0])[i]);
 }
@@ -951,7 +1007,41 @@ __device__ __forceinline__ void load_sample(const Workspace& ws, int group, int 
     }
 }
 
-__device__ void plane_stage(const Geometry& g, const Workspace& ws, int group, int allow_fallback, TileScratch* sh) {
+// Raw moments of ALL pixels of a group (torch_backend.py:409-410: fewer than 3 pixels pass the OD filter), by the
+// one workgroup of the per-tile stage: per-thread fp64 sums, fixed-order reduction.  Slow path.
+template <typename T>
+__device__ void all_pixel_moments(const T* __restrict__ images, const Geometry& g, int group, TileScratch* sh) {
+    const GroupPixels gp = group_pixels(g, group);
+    double acc[kPartial];
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
+    for (int64_t i = threadIdx.x; i < gp.count; i += blockDim.x) {
+        int64_t tile, p;
+        gp.locate(i, tile, p);
+        float od[3];
+        load_od_scalar<T>(images, g.pixels, tile, p, od);
+        const double x = od[0], y = od[1], z = od[2];
+        acc[0] += 1.0; acc[1] += x; acc[2] += y; acc[3] += z;
+        acc[4] += x * x; acc[5] += x * y; acc[6] += x * z; acc[7] += y * y; acc[8] += y * z; acc[9] += z * z;
+    }
+    const int wave = threadIdx.x / kWave, n_waves = blockDim.x / kWave;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) {
+        const double s = wave_total_f64(acc[k]);
+        if (lane_id() == kWave - 1) sh->stage[wave][k] = s;      // n_waves <= 64 rows
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartial) {
+        double s = 0.0;
+        for (int w = 0; w < n_waves; ++w) s += sh->stage[w][threadIdx.x];
+        sh->mom[kPartial + threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__device__ void plane_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int allow_fallback, TileScratch* sh) {
     GroupState& st = ws.state[group];
     SX_STAMP(st, 0);
     reset_scratch(sh);
@@ -963,18 +1053,23 @@ __device__ void plane_stage(const Geometry& g, const Workspace& ws, int group, i
         // thread per moment adds them in index order
         const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
         const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
-        const int rows = 32;
+        const int rows = 64;
         double running = 0.0;
         for (int64_t b0 = 0; b0 < nblk; b0 += rows) {
             const int live = (int)min((int64_t)rows, nblk - b0);
             __syncthreads();
-            if ((int)threadIdx.x < live * kMoments) sh->stage[threadIdx.x / kMoments][threadIdx.x % kMoments] = get(&ws.partial[(first + b0) * kMoments + threadIdx.x]);
+            if ((int)threadIdx.x < live * kPartial) sh->stage[threadIdx.x / kPartial][threadIdx.x % kPartial] = get(&ws.partial[(first + b0) * kPartial + threadIdx.x]);
             __syncthreads();
-            if (threadIdx.x < kMoments)
+            if (threadIdx.x < kPartial)
                 for (int b = 0; b < live; ++b) running += sh->stage[b][threadIdx.x];
         }
-        if (threadIdx.x < kMoments) sh->mom[threadIdx.x] = running;
+        if (threadIdx.x < kPartial) sh->mom[threadIdx.x] = running;
+        const GroupPixels gp = group_pixels(g, group);
+        if (threadIdx.x == kPartial) sh->mom[kPartial] = (double)gp.count;       // all-pixel set: the count is known,
+        if (threadIdx.x > kPartial && threadIdx.x < kMoments) sh->mom[threadIdx.x] = 0.0;   // the sums only matter in the fallback below
     }
+    __syncthreads();
+    if (allow_fallback && sh->mom[0] < 3.0) all_pixel_moments<T>(images, g, group, sh);     // uniform, rare (blank tiles)
     __syncthreads();
     SX_STAMP(st, 1);
     if (threadIdx.x == 0) {
@@ -1341,9 +1436,10 @@ __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __
 }
 
 
-__global__ __launch_bounds__(kGroupThreads) void plane_kernel(Geometry g, Workspace ws, int allow_fallback) {
+template <typename T>
+__global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restrict__ images, Geometry g, Workspace ws, int allow_fallback) {
     __shared__ TileScratch sh;
-    plane_stage(g, ws, blockIdx.x, allow_fallback, &sh);
+    plane_stage<T>(images, g, ws, blockIdx.x, allow_fallback, &sh);
 }
 
 template <typename T>
@@ -1374,11 +1470,15 @@ struct alignas(256) DFitState {
     int round[2];
 };
 
-__global__ void dfit_reduce_partials_kernel(const double* __restrict__ partial, int64_t nblk, double* __restrict__ moments) {
+__global__ void dfit_reduce_partials_kernel(const double* __restrict__ partial, int64_t nblk, double n_all, double* __restrict__ moments) {
     const int k = threadIdx.x;
     if (k >= kMoments) return;
     double s = 0.0;
-    for (int64_t b = 0; b < nblk; ++b) s += partial[b * kMoments + k];
+    if (k < kPartial) {
+        for (int64_t b = 0; b < nblk; ++b) s += partial[b * kPartial + k];
+    } else if (k == kPartial) {
+        s = n_all;        // all-pixel set: only its count is used by the distributed fit (no fallback there)
+    }
     moments[k] = s;
 }
 
@@ -1517,7 +1617,7 @@ template <typename T, int V>
 static int run_estimate(const T* images, const Geometry& g, const Workspace& ws, int n_groups, int allow_fallback, const float* tmc, float* he_out, float* max_c_out, hipStream_t stream) {
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     hipLaunchKernelGGL((stats_kernel<T, V>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
-    hipLaunchKernelGGL(plane_kernel, dim3(n_groups), dim3(kGroupThreads), 0, stream, g, ws, allow_fallback);
+    hipLaunchKernelGGL((plane_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws, allow_fallback);
     hipLaunchKernelGGL((bracket_kernel<T, V, false>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((stain_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((bracket_kernel<T, V, true>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
@@ -1583,7 +1683,7 @@ static int dfit_moments_typed(const void* images, const Geometry& g0, const Work
         hipLaunchKernelGGL((stats_kernel<T, W>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
     else
         hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
-    hipLaunchKernelGGL(dfit_reduce_partials_kernel, dim3(1), dim3(64), 0, stream, ws.partial, (int64_t)grid, moments);
+    hipLaunchKernelGGL(dfit_reduce_partials_kernel, dim3(1), dim3(64), 0, stream, ws.partial, (int64_t)grid, (double)(g.n_tiles * g.pixels), moments);
     return check_launch("macenko dfit moments");
 }
 
