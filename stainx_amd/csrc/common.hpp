@@ -118,7 +118,7 @@ __device__ __forceinline__ void store_pack_stream(T* __restrict__ p, const T (&v
 // ---- order-preserving uint32 image of a float (radix / bracket selection keys) ------------------
 __device__ __forceinline__ uint32_t float_key(float f) {
     const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);      // negative: ~u, positive: u | sign bit -- three ops, no select
 }
 __device__ __forceinline__ float key_float(uint32_t k) {
     const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;

@@ -171,8 +171,8 @@ __device__ __forceinline__ bool od_selected(const float od[3], bool use_all) {
 // (one v_rcp_f32 instead of a ~40-instruction atan2f).  The two selected keys per tile are turned back into
 // phi by angle_from_key() in double precision; the difference from atan2f of the same pixel is ~1e-7 rad.
 __device__ __forceinline__ float diamond_angle(float t1, float t0) {
-    const float den = fabsf(t0) + fabsf(t1);
-    const float r = den > 0.0f ? t1 * __frcp_rn(den) : 0.0f;
+    const float den = fmaxf(fabsf(t0) + fabsf(t1), 1e-30f);      // t0 = t1 = 0 -> r = 0
+    const float r = t1 * __builtin_amdgcn_rcpf(den);               // bare v_rcp_f32 (1 ulp): the key only has to be the same everywhere
     return t0 >= 0.0f ? r : (t1 >= 0.0f ? 2.0f - r : -2.0f - r);
 }
 
@@ -844,14 +844,16 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
     if (threadIdx.x < 2) sh->below[threadIdx.x] = 0;
     __syncthreads();
 
-    const bool use_all = kConc ? true : (rec.use_all != 0);
+    // the OD filter as one comparison: min(OD) >= threshold, with threshold -inf when every pixel is selected
+    const float threshold = (kConc || rec.use_all != 0) ? -__builtin_huge_valf() : kBeta;
     const uint32_t lo_a = rec.lo[0], hi_a = rec.hi[0], lo_b = rec.lo[1], hi_b = rec.hi[1];
     uint32_t* cand_a = ws.cand + ((size_t)group * kSlots + s0) * g.cap;
     uint32_t* cand_b = cand_a + g.cap;
     uint32_t* queue_a = sh->keys[wave][0];
     uint32_t* queue_b = sh->keys[wave][1];
+    // wave-uniform counters (SGPRs): comparisons leave lane masks, counting is a scalar popcount
     uint32_t below_a = 0, below_b = 0;
-    uint32_t n_a = 0, n_b = 0;        // queued keys of this wave: uniform
+    uint32_t n_a = 0, n_b = 0;
 
     for (; base < p_end; base += (int64_t)TPB * V) {
         const bool live = base + mine < p_end;
@@ -870,7 +872,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             float od[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
-            const bool valid = live && od_selected(od, use_all);
+            const bool valid = live && fminf(od[0], fminf(od[1], od[2])) >= threshold;     // torch_backend.py:404-405
             uint32_t key_a, key_b;
             if constexpr (kConc) {
                 float c0, c1;
@@ -880,8 +882,8 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             } else {
                 key_a = key_b = angle_key(od, rec.coef);
             }
-            below_a += (valid && key_a < lo_a) ? 1u : 0u;
-            below_b += (valid && key_b < lo_b) ? 1u : 0u;
+            below_a += (uint32_t)__popcll(__ballot(valid && key_a < lo_a));
+            below_b += (uint32_t)__popcll(__ballot(valid && key_b < lo_b));
             const bool in_a = valid && key_a >= lo_a && key_a <= hi_a, in_b = valid && key_b >= lo_b && key_b <= hi_b;
             const uint64_t m_a = __ballot(in_a), m_b = __ballot(in_b);
             if (in_a) queue_a[n_a + rank_in_mask(m_a)] = key_a;
@@ -920,10 +922,9 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
         }
     }
 
-    const uint32_t wa = wave_total_u32(below_a), wb = wave_total_u32(below_b);
-    if (lane_id() == 0) {
-        if (wa) atomicAdd(&sh->below[0], wa);
-        if (wb) atomicAdd(&sh->below[1], wb);
+    if (lane_id() == 0) {      // the counts are already wave totals
+        if (below_a) atomicAdd(&sh->below[0], below_a);
+        if (below_b) atomicAdd(&sh->below[1], below_b);
     }
     __syncthreads();
     if (threadIdx.x < 2) {
