@@ -67,7 +67,7 @@ struct alignas(256) GroupState {
     float vecs[6];                // (3,2) row-major, columns [middle, largest] eigenvalue
     float he[6];                  // (3,2) row-major HE_source
     float pinv[6];                // (2,3) row-major pseudo-inverse of HE_source
-    float phi[2];
+    uint32_t phi_key[2];          // the two selected angle keys
     float max_c[2];
     unsigned long long n_sel;     // pixels in the selection set (kept by the OD filter, or all)
     unsigned long long rank[kSlots];   // wanted 0-based rank inside the selection set
@@ -220,9 +220,9 @@ __device__ __forceinline__ void load_od_scalar(const T* __restrict__ images, int
 // leaves a 1e-7-times smaller off-diagonal for the next sweep.
 #define SX_JACOBI_ROTATE(app, aqq, apq, arp, arq, v0p, v0q, v1p, v1q, v2p, v2q)            \
     if ((apq) != 0.0) {                                                                      \
-        const float theta = (float)((aqq) - (app)) / (float)(2.0 * (apq));                   \
-        const float tf = copysignf(1.0f, theta) / (fabsf(theta) + sqrtf(fmaf(theta, theta, 1.0f))); \
-        const float cf = rsqrtf(fmaf(tf, tf, 1.0f));                                         \
+        const float theta = (float)((aqq) - (app)) * __builtin_amdgcn_rcpf((float)(2.0 * (apq))); \
+        const float tf = copysignf(1.0f, theta) * __builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.0f))); \
+        const float cf = __builtin_amdgcn_rsqf(fmaf(tf, tf, 1.0f));                          \
         double c = (double)cf, sn = (double)(tf * cf);                                       \
         const double fix = 1.5 - 0.5 * (c * c + sn * sn);                                    \
         c *= fix;                                                                            \
@@ -254,7 +254,7 @@ __device__ void jacobi_eigh3(const double a_in[9], double w[3], double q[9]) {
     for (int sweep = 0; sweep < 32; ++sweep) {
         const double off = a01 * a01 + a02 * a02 + a12 * a12;
         const double diag = a00 * a00 + a11 * a11 + a22 * a22;
-        if (off <= 1e-36 * diag || off == 0.0) break;
+        if (off <= 1e-30 * diag || off == 0.0) break;      // |off|/|diag| <= 1e-15
         SX_JACOBI_ROTATE(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21)   // (0,1), r = 2
         SX_JACOBI_ROTATE(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22)   // (0,2), r = 1
         SX_JACOBI_ROTATE(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22)   // (1,2), r = 0
@@ -311,9 +311,35 @@ __device__ void plane_from_moments(const double* mom, bool allow_fallback, doubl
     n_sel = (unsigned long long)cnt;
 }
 
-// Angle percentiles -> extreme stain vectors -> HE_source (H before E) -> its (2,3) pseudo-inverse.
-__device__ void stain_vectors_and_pinv(const float* vecs, float phi_lo, float phi_hi, float* he_out, float* pinv_out) {
-    const float cl = cosf(phi_lo), sl = sinf(phi_lo), ch = cosf(phi_hi), sh = sinf(phi_hi);   // torch_backend.py:427-430
+// (cos phi, sin phi) of the angle a diamond key stands for, without going through phi: the point (x, y) on the
+// diamond |x| + |y| = 1 the key encodes, normalised (fp64; the reciprocal root is a v_rsq_f32 seed + one Newton
+// step).  Differs from cosf/sinf of the fp32 angle (torch_backend.py:427-430) by ~1e-7.
+__device__ __forceinline__ void direction_from_key(uint32_t key, float& c, float& s) {
+    const double d = (double)key_float(key);
+    double x, y;
+    if (d > 1.0) {            // second quadrant: d = 2 - r
+        y = 2.0 - d;
+        x = -(1.0 - y);
+    } else if (d < -1.0) {    // third quadrant: d = -2 - r, r in (-1,0]
+        y = -2.0 - d;
+        x = -(1.0 + y);
+    } else {
+        y = d;
+        x = 1.0 - fabs(d);
+    }
+    const double n2 = x * x + y * y;                      // in [0.5, 1]
+    double inv = (double)__builtin_amdgcn_rsqf((float)n2);
+    inv = inv * (1.5 - 0.5 * n2 * inv * inv);
+    inv = inv * (1.5 - 0.5 * n2 * inv * inv);
+    c = (float)(x * inv);
+    s = (float)(y * inv);
+}
+
+// Angle percentiles (as keys) -> extreme stain vectors -> HE_source (H before E) -> its (2,3) pseudo-inverse.
+__device__ void stain_vectors_and_pinv(const float* vecs, uint32_t key_lo, uint32_t key_hi, float* he_out, float* pinv_out) {
+    float cl, sl, ch, sh;
+    direction_from_key(key_lo, cl, sl);
+    direction_from_key(key_hi, ch, sh);
     float vmin[3], vmax[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -457,6 +483,26 @@ __device__ __forceinline__ double bin_scale_for(uint32_t lo, uint32_t hi) {
     return (span > 0.0 && span < 1e300) ? 256.0 / span : 0.0;
 }
 
+// The keys bin b holds, as an inclusive range [first, last] (bin_of is monotone in the key): the edge value is
+// inverted in fp64 and walked to the exact boundary with bin_of itself, so `first <= key <= last` is the same
+// predicate as `bin_of(key) == b` at two integer comparisons per key instead of six fp64 operations.
+__device__ __forceinline__ uint32_t bin_lower_edge(uint32_t bin, double origin, double scale, double inv_scale) {      // smallest key with bin_of(key) >= bin, bin in 1..255
+    uint32_t k = float_key((float)(origin + (double)bin * inv_scale));
+    while (k > 0u && bin_of(k - 1u, origin, scale) >= bin) --k;
+    while (k < 0xFFFFFFFFu && bin_of(k, origin, scale) < bin) ++k;
+    return k;
+}
+__device__ __forceinline__ void bin_key_range(uint32_t b, double origin, double scale, uint32_t& first, uint32_t& last) {
+    if (!(scale > 0.0)) {          // degenerate range: everything is in bin 0
+        first = b == 0 ? 0u : 1u;
+        last = b == 0 ? 0xFFFFFFFFu : 0u;
+        return;
+    }
+    const double inv_scale = 1.0 / scale;
+    first = b == 0 ? 0u : bin_lower_edge(b, origin, scale, inv_scale);
+    last = b >= 255u ? 0xFFFFFFFFu : bin_lower_edge(b + 1u, origin, scale, inv_scale) - 1u;
+}
+
 // LDS scratch of a per-tile stage (one workgroup).  The sample (_s) and candidate (_c) selections have their own
 // histograms, lists and counters, so one reset at the top of the kernel serves both.
 struct alignas(16) TileScratch {
@@ -470,7 +516,7 @@ struct alignas(16) TileScratch {
     double stage[64][kPartial];
     unsigned long long radix_rank, n_sel;
     uint32_t bin_s[4], rank_in_bin_s[4], count_s[4], result_s[4];
-    uint32_t bin_c[2], rank_in_bin_c[2], count_c[2], result_c[2];
+    uint32_t range_c[2][2], rank_in_bin_c[2], count_c[2], result_c[2];
     uint32_t range_lo[2], range_hi[2], radix_digit;
     uint32_t valid;
     float coef[6];
@@ -1235,23 +1281,25 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
     }
     __syncthreads();
     const int wave = threadIdx.x / kWave;
-    if (wave < 2 && ok[wave]) {
+    // (no runtime indexing of the register arrays: that would send the whole prefetch to scratch memory)
+    const bool second = wave == 1;
+    if (wave < 2 && (second ? ok[1] : ok[0])) {
         uint32_t b, rb;
-        scan_pick32(sh->hist_c[wave], want_in[wave], b, rb);
+        scan_pick32(sh->hist_c[wave], second ? want_in[1] : want_in[0], b, rb);
         if (lane_id() == 0) {
-            sh->bin_c[wave] = b;
             sh->rank_in_bin_c[wave] = rb;
+            bin_key_range(b, second ? pf.origin[1] : pf.origin[0], second ? pf.scale[1] : pf.scale[0], sh->range_c[wave][0], sh->range_c[wave][1]);
         }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (!ok[j]) continue;
-        const uint32_t b = sh->bin_c[j], n = pf.ncand[j];
+        const uint32_t k_first = sh->range_c[j][0], k_last = sh->range_c[j][1], n = pf.ncand[j];
 #pragma unroll
         for (int u = 0; u < kPrefetchCand; ++u) {
             const uint32_t idx = u * kGroupThreads + threadIdx.x, k = pf.cand[j][u];
-            if (idx < n && bin_of(k, pf.origin[j], pf.scale[j]) == b) {
+            if (idx < n && k >= k_first && k <= k_last) {
                 const uint32_t at = atomicAdd(&sh->count_c[j], 1u);
                 if (at < (uint32_t)kShortList) sh->list_c[j][at] = k;
             }
@@ -1268,7 +1316,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t idx = base + u * kGroupThreads;
-                if (idx < n && bin_of(k[u], pf.origin[j], pf.scale[j]) == b) {
+                if (idx < n && k[u] >= k_first && k[u] <= k_last) {
                     const uint32_t at = atomicAdd(&sh->count_c[j], 1u);
                     if (at < (uint32_t)kShortList) sh->list_c[j][at] = k[u];
                 }
@@ -1278,7 +1326,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
     __syncthreads();
     {   // rank counting of the two short lists side by side, half the workgroup each
         const uint32_t per = blockDim.x / 2, j = threadIdx.x / per;
-        if (ok[j] && sh->count_c[j] <= (uint32_t)kShortList) rank_pick(sh->list_c[j], sh->count_c[j], sh->rank_in_bin_c[j], threadIdx.x - j * per, per, &sh->result_c[j]);
+        if ((j ? ok[1] : ok[0]) && sh->count_c[j] <= (uint32_t)kShortList) rank_pick(sh->list_c[j], sh->count_c[j], sh->rank_in_bin_c[j], threadIdx.x - j * per, per, &sh->result_c[j]);
     }
     __syncthreads();
 #pragma unroll
@@ -1318,17 +1366,16 @@ __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, con
     resolve_pair<T>(images, g, ws, group, 0, vecs, use_all, pf, phi_key, sh);
     SX_STAMP(st, 7);
     if (threadIdx.x == 0) {
-        const float phi_lo = angle_from_key(phi_key[0]), phi_hi = angle_from_key(phi_key[1]);
         float he[6], pinv[6];
-        stain_vectors_and_pinv(vecs, phi_lo, phi_hi, he, pinv);
+        stain_vectors_and_pinv(vecs, phi_key[0], phi_key[1], he, pinv);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             put(&st.he[i], he[i]);
             put(&st.pinv[i], pinv[i]);
             sh->coef[i] = pinv[i];
         }
-        put(&st.phi[0], phi_lo);
-        put(&st.phi[1], phi_hi);
+        put(&st.phi_key[0], phi_key[0]);       // phi itself is only worked out for sx_macenko_tile_params
+        put(&st.phi_key[1], phi_key[1]);
         put(&st.ncand_seen[0], pf.ncand[0]);
         put(&st.ncand_seen[1], pf.ncand[1]);
     }
@@ -1568,7 +1615,7 @@ __global__ __launch_bounds__(128) void dfit_advance_kernel(DFitState* __restrict
         const float phi_lo = angle_from_key(st->prefix[0]), phi_hi = angle_from_key(st->prefix[1]);
         st->phi[0] = phi_lo;
         st->phi[1] = phi_hi;
-        stain_vectors_and_pinv(st->vecs, phi_lo, phi_hi, st->he, st->pinv);
+        stain_vectors_and_pinv(st->vecs, st->prefix[0], st->prefix[1], st->he, st->pinv);
         st->rank[2] = st->rank[3] = nearest_rank_index(99.0, st->n_all);
     } else {
         st->max_c[0] = key_float(st->prefix[2]);
@@ -1589,8 +1636,8 @@ __global__ void export_params_kernel(const GroupState* __restrict__ state, int64
     o[0] = (float)st.n_sel;
     o[1] = (float)st.use_all;
     for (int i = 0; i < 6; ++i) o[2 + i] = st.vecs[i];
-    o[8] = st.phi[0];
-    o[9] = st.phi[1];
+    o[8] = angle_from_key(st.phi_key[0]);
+    o[9] = angle_from_key(st.phi_key[1]);
     for (int i = 0; i < 6; ++i) o[10 + i] = st.he[i];
     o[16] = st.max_c[0];
     o[17] = st.max_c[1];
