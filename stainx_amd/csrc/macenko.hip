@@ -156,9 +156,13 @@ template <typename U> __device__ __forceinline__ U get(const U* p) { return *p; 
 // `raw` is the unit value for float inputs and the integer grey level for uint8 (the reference's u/255*255 is u
 // up to one rounding).
 template <typename T>
-__device__ __forceinline__ float optical_density(float raw) {
+__device__ __forceinline__ float log2_level(float raw) {      // log2(255 x + 1): the argument is >= 1 for image data, bare v_log_f32
     const float t = sizeof(T) == 1 ? raw + 1.0f : fmaf(raw, 255.0f, 1.0f);
-    return fmaf(-kLn2, __log2f(t), kLnIo);
+    return __log2f(t);
+}
+template <typename T>
+__device__ __forceinline__ float optical_density(float raw) {
+    return fmaf(-kLn2, log2_level<T>(raw), kLnIo);
 }
 
 __device__ __forceinline__ bool od_selected(const float od[3], bool use_all) {
@@ -752,6 +756,8 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     const uint32_t sample_count = (uint32_t)g.sample_count;
     const uint32_t mask = (uint32_t)g.sample_stride - 1u;          // stride is a power of two
     const int shift = 31 - __clz(g.sample_stride);
+    constexpr int kLog2V = V == 16 ? 4 : V == 8 ? 3 : V == 4 ? 2 : V == 2 ? 1 : 0;
+    const bool by_pack = shift >= kLog2V;      // a pack lies inside one sample cell (always, except for tiles of < 4096*V pixels)
 
     // products and the sums over 32 pixels of a lane in fp32, everything beyond in fp64: the fp32 rounding is
     // unbiased and averages out over the tile (~4e-9 on a covariance entry, measured against the fp64 covariance
@@ -770,12 +776,32 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
             float u[3][V];
 #pragma unroll
             for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
-            const uint32_t gpos = group_offset + (uint32_t)p;      // position inside the group
+            // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
+            // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
+            const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset(j, shift);
+            if (by_pack && (((gpos & mask) ^ off) >> kLog2V) == 0u && j < sample_count) {
+                float raw[3] = {u[0][0], u[1][0], u[2][0]};
+#pragma unroll
+                for (int i = 1; i < V; ++i)
+                    if ((int)(off & (uint32_t)(V - 1)) == i) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) raw[c] = u[c][i];
+                    }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], optical_density<T>(raw[c]));
+            }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float od[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
+                if (!by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
+                    const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
+                    if ((pos & mask) == sample_offset(jj, shift) && jj < sample_count) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + jj], od[c]);
+                    }
+                }
                 const float keep = od_selected(od, false) ? 1.0f : 0.0f;
                 const float k0 = keep * od[0], k1 = keep * od[1], k2 = keep * od[2];
                 m[0] += keep;
@@ -788,13 +814,6 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
                 m[7] = fmaf(k1, od[1], m[7]);
                 m[8] = fmaf(k1, od[2], m[8]);
                 m[9] = fmaf(k2, od[2], m[9]);
-                // sample j sits in [j*stride, (j+1)*stride) at a hashed offset (a fixed offset would alias with the image
-                // width: stride 1024 on a 2048-wide tile samples two columns only)
-                const uint32_t pos = gpos + (uint32_t)i, j = pos >> shift;
-                if ((pos & mask) == sample_offset(j, shift) && j < sample_count) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od[c]);
-                }
             }
         }
 #pragma unroll
@@ -994,13 +1013,32 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
     O* dst = out + tile * 3 * g.pixels;
     const StageRecord* rec = &ws.state[tile].rec[2];
 
-    float pinv[6], sm[6];
+    // The whole chain OD -> C = pinv OD -> C * (tmc/maxC) -> SM C -> 240 exp(-.) (torch_backend.py:444-458) is linear between
+    // the logarithm and the exponential, so it is folded into one 3x3 matrix per tile (fp64, then fp32):
+    //   rgb_c = 2^x_c,   x_c = sum_j M[c][j] L_j + log2(240) (1 - sum_j M[c][j]),   L_j = log2(255 x_j + 1),
+    //   M = SM diag(scale) pinv      (ln2 * log2e = 1 cancels between OD = ln240 - ln2 L and exp(-y) = 2^(-y log2e))
+    // 9 fma per pixel instead of 20 multiply-adds; differs from the reference's operation order by ~1e-6 relative.
+    float m[3][3], k[3];
+    {
+        double pinv[6], sm[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        pinv[i] = get(&rec->coef[i]);
-        sm[i] = stain_matrix[i];
+        for (int i = 0; i < 6; ++i) {
+            pinv[i] = (double)get(&rec->coef[i]);
+            sm[i] = (double)stain_matrix[i];
+        }
+        const double s0 = (double)get(&rec->scale[0]), s1 = (double)get(&rec->scale[1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double row = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double v = sm[c * 2] * s0 * pinv[j] + sm[c * 2 + 1] * s1 * pinv[3 + j];
+                m[c][j] = (float)v;
+                row += (double)m[c][j];
+            }
+            k[c] = (float)(7.90689059560851852932 * (1.0 - row));      // log2(240)
+        }
     }
-    const float s0 = get(&rec->scale[0]), s1 = get(&rec->scale[1]);
 
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
         float u[3][V];
@@ -1009,16 +1047,13 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
         O res[3][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            float od[3], c0, c1;
+            float l[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
-            concentration(od, pinv, c0, c1);
-            c0 *= s0;                                                   // :453
-            c1 *= s1;
+            for (int c = 0; c < 3; ++c) l[c] = log2_level<T>(u[c][i]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float od_new = fmaf(sm[c * 2 + 1], c1, sm[c * 2] * c0);         // :455
-                float rgb = kIo * exp2f(-od_new * kLog2e);                            // :458  (v_exp_f32)
+                const float x = fmaf(m[c][2], l[2], fmaf(m[c][1], l[1], fmaf(m[c][0], l[0], k[c])));
+                float rgb = __builtin_amdgcn_exp2f(x);                                // bare v_exp_f32: a result below 2^-126 is 0 either way after the cast
                 rgb = fminf(fmaxf(rgb, 0.0f), 255.0f);                                // :459, :128
                 if constexpr (kUnit) {
                     // cast to the input dtype first, then /255 in that dtype (_template.py:111-112);
