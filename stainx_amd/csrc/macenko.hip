@@ -921,7 +921,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
     uint32_t n_a = 0, n_b = 0;
 
     for (; base < p_end; base += (int64_t)TPB * V) {
-        const bool live = base + mine < p_end;
+        const uint64_t live_mask = __builtin_amdgcn_ballot_w64(base + mine < p_end);
         float u[3][V];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -937,7 +937,6 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             float od[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
-            const bool valid = live && fminf(od[0], fminf(od[1], od[2])) >= threshold;     // torch_backend.py:404-405
             uint32_t key_a, key_b;
             if constexpr (kConc) {
                 float c0, c1;
@@ -947,12 +946,17 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             } else {
                 key_a = key_b = angle_key(od, rec.coef);
             }
-            below_a += (uint32_t)__popcll(__ballot(valid && key_a < lo_a));
-            below_b += (uint32_t)__popcll(__ballot(valid && key_b < lo_b));
-            const bool in_a = valid && key_a >= lo_a && key_a <= hi_a, in_b = valid && key_b >= lo_b && key_b <= hi_b;
-            const uint64_t m_a = __ballot(in_a), m_b = __ballot(in_b);
-            if (in_a) queue_a[n_a + rank_in_mask(m_a)] = key_a;
-            if (in_b) queue_b[n_b + rank_in_mask(m_b)] = key_b;
+            // five comparisons per pixel; everything else happens on their lane masks with scalar instructions (the
+            // ballot of a bare comparison is the comparison's own result register, inverse_ballot makes a mask the
+            // branch condition again -- no 0/1 values in vector registers)
+            const uint64_t valid = __builtin_amdgcn_ballot_w64(fminf(od[0], fminf(od[1], od[2])) >= threshold) & live_mask;     // torch_backend.py:404-405
+            const uint64_t lt_a = __builtin_amdgcn_ballot_w64(key_a < lo_a), le_a = __builtin_amdgcn_ballot_w64(key_a <= hi_a);
+            const uint64_t lt_b = __builtin_amdgcn_ballot_w64(key_b < lo_b), le_b = __builtin_amdgcn_ballot_w64(key_b <= hi_b);
+            below_a += (uint32_t)__popcll(valid & lt_a);
+            below_b += (uint32_t)__popcll(valid & lt_b);
+            const uint64_t m_a = valid & ~lt_a & le_a, m_b = valid & ~lt_b & le_b;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_a)) queue_a[n_a + rank_in_mask(m_a)] = key_a;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_b)) queue_b[n_b + rank_in_mask(m_b)] = key_b;
             n_a += (uint32_t)__popcll(m_a);
             n_b += (uint32_t)__popcll(m_b);
             if ((i + 1) % kCheck == 0) {      // the next kCheck pixels add at most kCheck * 64 keys
