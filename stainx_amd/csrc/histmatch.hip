@@ -6,8 +6,9 @@
 // -> 256-entry float LUT with linear interpolation (:254-281), gather (:285), and the output range /
 // dtype rules (:288-298).
 //
-// Kernels: (1) histogram -- 16-byte loads, one LDS sub-histogram per wave so lanes of different waves
-// never contend, integer adds only (bit-exact, order independent); (2) one small workgroup builds
+// Kernels: (1) histogram -- 16-byte loads; planar layout: one plane chunk per workgroup and 32 bank-striped copies of
+// the histogram in LDS (no bank conflicts); interleaved layout: one LDS sub-histogram per wave; integer adds only
+// (bit-exact, order independent); (2) one small workgroup builds
 // the 3 x 256 LUT (sequential double-precision prefix sums rounded to float per entry, exactly what
 // torch.cumsum does on CPU floats) and the LUT in the OUTPUT element type; (3) apply -- LDS-resident
 // typed LUT, 16-byte loads and stores, writes the final dtype directly (the reference's native path
@@ -87,6 +88,39 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const T* __restrict
     }
 }
 
+// Planar layout, 16-byte packs: a workgroup takes one chunk of ONE channel plane, so a single 256-bin histogram is live
+// and LDS has room for 32 copies of it, copy k in bank k: lane l only ever touches bank l % 32, so the 64 lanes of an
+// atomic instruction never collide on a bank (random grey levels into a single histogram: ~5 of 64 lanes per bank and
+// 13 cycles per instruction measured; this form is bound by the HBM read instead).  Integer adds: bit-exact.
+constexpr int kCopies = 32;
+constexpr int kPlaneChunk = 65536;      // elements of one plane per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void histogram_planar_kernel(const T* __restrict__ images, Layout lay, int chunks_per_plane, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[kBins][kCopies];
+    for (int i = threadIdx.x; i < kBins * kCopies; i += kThreads) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    constexpr int V = VecOf<T>::n;
+    const int64_t plane = blockIdx.x / chunks_per_plane, chunk = blockIdx.x % chunks_per_plane;
+    const int channel = (int)(plane % 3);
+    const T* src = images + plane * lay.pixels;
+    const int64_t begin = chunk * (int64_t)kPlaneChunk, end = min(begin + (int64_t)kPlaneChunk, lay.pixels);
+    uint32_t* mine = &hist[0][threadIdx.x & (kCopies - 1)];
+    for (int64_t e = begin + (int64_t)threadIdx.x * V; e < end; e += (int64_t)kThreads * V) {
+        const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(src + e);
+#pragma unroll
+        for (int i = 0; i < V; ++i) atomicAdd(&mine[grey_level<T>(pk.v[i]) * kCopies], 1u);
+    }
+    __syncthreads();
+    {   // thread t adds up the copies of bin t, starting at its own bank
+        const int t = threadIdx.x;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < kCopies; ++k) sum += hist[t][(t + k) & (kCopies - 1)];
+        if (sum) atomicAdd(&counts[channel * kBins + t], sum);
+    }
+}
+
 // fit: normalised histogram  counts / (sum(counts) + 1e-8)  in float32 (torch_backend.py:139-141)
 __global__ void normalise_kernel(const uint32_t* __restrict__ counts, float* __restrict__ hist_out) {
     const int c = blockIdx.x;
@@ -113,7 +147,7 @@ __global__ void widen_kernel(const uint32_t* __restrict__ counts, unsigned long 
 
 // One workgroup of 256 threads per channel.  InT decides the range rules of the output (:288-298).
 template <typename T>
-__global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, const unsigned long long* __restrict__ counts, const float* __restrict__ ref_hist, double num_pixels) {
+__global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, const unsigned long long* __restrict__ counts, const uint32_t* __restrict__ counts32, const float* __restrict__ ref_hist, double num_pixels) {
     const int c = blockIdx.x, t = threadIdx.x;
     __shared__ float src_cdf[kBins], ref_cdf[kBins];
     __shared__ float src_term[kBins], ref_term[kBins];
@@ -126,7 +160,9 @@ __global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, co
         ref_denom_s = (float)tot + 1e-8f;
     }
     // source: counts / float(num_pixels + 1e-8) (:235)
-    src_term[t] = (float)counts[c * kBins + t] / (float)(num_pixels + 1e-8);
+    // (the local histogram is read as it was counted; counts pooled over ranks arrive widened to 64 bits)
+    const unsigned long long count = counts32 ? (unsigned long long)counts32[c * kBins + t] : counts[c * kBins + t];
+    src_term[t] = (float)count / (float)(num_pixels + 1e-8);
     __syncthreads();
     ref_term[t] = ref_hist[c * kBins + t] / ref_denom_s;
     __syncthreads();
@@ -214,10 +250,14 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
     const int64_t per_block = (int64_t)kThreads * (vec ? V : 1) * 4;
     const unsigned grid = (unsigned)std::min<int64_t>((total + per_block - 1) / per_block, 256 * 8);
     const unsigned long long* lut_counts = counts_in;
+    const uint32_t* lut_counts32 = nullptr;
     double lut_pixels = n_total;
     if (!counts_in) {
         if (hipMemsetAsync(tab->counts, 0, sizeof(tab->counts), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
-        if (vec)
+        if (vec && !channels_last) {
+            const int chunks_per_plane = (int)((lay.pixels + kPlaneChunk - 1) / kPlaneChunk);
+            hipLaunchKernelGGL((histogram_planar_kernel<T>), dim3((unsigned)(n * 3 * chunks_per_plane)), dim3(kThreads), 0, stream, in, lay, chunks_per_plane, &tab->counts[0][0]);
+        } else if (vec)
             hipLaunchKernelGGL((histogram_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
         else
             hipLaunchKernelGGL((histogram_kernel<T, false>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
@@ -225,13 +265,14 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
             hipLaunchKernelGGL(normalise_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], hist_out);
             return check_launch("histogram fit");
         }
-        unsigned long long* wide = counts_out ? counts_out : &tab->counts64[0][0];
-        hipLaunchKernelGGL(widen_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], wide);
-        if (counts_out) return check_launch("histogram counts");
-        lut_counts = wide;
+        if (counts_out) {
+            hipLaunchKernelGGL(widen_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], counts_out);
+            return check_launch("histogram counts");
+        }
+        lut_counts32 = &tab->counts[0][0];
         lut_pixels = (double)(n * h * w);
     }
-    hipLaunchKernelGGL((lut_kernel<T>), dim3(3), dim3(kBins), 0, stream, tab, lut_counts, ref_hist, lut_pixels);
+    hipLaunchKernelGGL((lut_kernel<T>), dim3(3), dim3(kBins), 0, stream, tab, lut_counts, lut_counts32, ref_hist, lut_pixels);
     if (vec)
         hipLaunchKernelGGL((apply_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, static_cast<T*>(out), lay, tab);
     else
