@@ -18,6 +18,7 @@ LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libstainx_hip.so"
 
 SX_OK, SX_ERR_BAD_ARG, SX_ERR_DTYPE, SX_ERR_WORKSPACE, SX_ERR_LAUNCH = range(5)
 MACENKO_NORMALIZE_0_1 = 1
+MACENKO_CHANNELS_LAST = 2
 MACENKO_PARAM_FLOATS = 48
 
 DTYPE_CODES = {torch.uint8: 0, torch.float16: 1, torch.bfloat16: 2, torch.float32: 3, torch.float64: 4}

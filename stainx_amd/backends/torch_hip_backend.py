@@ -65,26 +65,33 @@ class MacenkoHIP(TorchHIPBackendBase):
         if images.shape[1] != 3:
             raise ValueError(f"Macenko {what} expects 3 channels in dim 1 (NCHW), got C={images.shape[1]} with shape {tuple(images.shape)}")
 
-    def transform(self, images: torch.Tensor, stain_matrix: torch.Tensor, target_max_conc: torch.Tensor, *, normalize_to_0_1: bool = False) -> torch.Tensor:
+    def transform(self, images: torch.Tensor, stain_matrix: torch.Tensor, target_max_conc: torch.Tensor, *, normalize_to_0_1: bool = False,
+                  channels_last: bool = False) -> torch.Tensor:
+        """``channels_last=True`` (an extension; the reference takes NCHW only): ``images`` is (N,H,W,3) as decoders and PIL
+        hand tiles over, and so is the result -- the permute + copy a caller would otherwise do first is fused away."""
         images = images.to(self.device)
         if tuple(stain_matrix.shape) != (3, 2):
             raise ValueError(f"stain_matrix must have shape (3, 2), got {stain_matrix.shape}")
-        self._check_images(images, "transform")
+        if channels_last:
+            if images.dim() != 4 or images.shape[3] != 3:
+                raise ValueError(f"Macenko transform with channels_last expects NHWC images with C=3, got shape {tuple(images.shape)}")
+        else:
+            self._check_images(images, "transform")
         sm = self._f32(stain_matrix)
         tmc = self._f32(target_max_conc).flatten()
         if tmc.numel() != 2:
             raise ValueError(f"target_max_conc must have 2 elements, got {tmc.numel()}")
         images = images.contiguous()
-        n, _, h, w = images.shape
+        n, h, w = (images.shape[0], images.shape[1], images.shape[2]) if channels_last else (images.shape[0], images.shape[2], images.shape[3])
         code = _dtype_code(images)
         out_dtype = torch.float32 if (normalize_to_0_1 and images.dtype == torch.uint8) else images.dtype
-        out = torch.empty((n, 3, h, w), dtype=out_dtype, device=self.device)
+        out = torch.empty(tuple(images.shape), dtype=out_dtype, device=self.device)
         if n == 0 or h * w == 0:
             return out
         with torch.cuda.device(self.device):
             nbytes = self._lib.sx_macenko_workspace_bytes(n, h, w)
             ws = self._scratch.get(nbytes, self.device)
-            flags = _native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0
+            flags = (_native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0) | (_native.MACENKO_CHANNELS_LAST if channels_last else 0)
             rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),
                                                 flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_transform")

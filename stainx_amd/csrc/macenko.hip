@@ -86,6 +86,7 @@ struct Geometry {
     int pooled;                   // 1: one group over all tiles (fit), 0: one group per tile
     int sample_stride, sample_count;   // sample j = pixel j*stride of the group, j < count
     uint32_t cap;                 // candidate keys per selection slot
+    int interleaved;              // 1: tiles are (H,W,3) -- the three values of a pixel side by side -- instead of three planes
 };
 
 struct Workspace {
@@ -207,11 +208,48 @@ __device__ __forceinline__ void concentration(const float od[3], const float* __
     c1 = fmaf(od[2], pinv[5], fmaf(od[1], pinv[4], od[0] * pinv[3]));
 }
 
-template <typename T>
-__device__ __forceinline__ void load_od_scalar(const T* __restrict__ images, int64_t pixels, int64_t tile, int64_t p, float od[3]) {
-    const T* base = images + tile * 3 * pixels + p;
+// The V pixels starting at pixel p of a tile, as raw channel values u[c][i]; the layout is a compile-time choice (a run-time
+// branch here costs the planar path dearly: uint8 146 -> 259 us/call measured).  Planar tiles: one 16-byte pack per plane.
+// Interleaved tiles (H,W,3): the 3V values lie side by side -- three packs, de-interleaved in registers (for free: the
+// indices are compile-time constants).
+template <typename T, int V, bool kInter>
+__device__ __forceinline__ void load_pixels(const T* __restrict__ img, int64_t pixels, int64_t p, float (&u)[3][V]) {
+    if constexpr (kInter) {
+        float flat[3][V];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(raw_value<T>(base[c * pixels]));
+        for (int k = 0; k < 3; ++k) load_raw<T, V>(img + 3 * p + k * V, flat[k]);
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) u[c][i] = flat[(3 * i + c) / V][(3 * i + c) % V];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * pixels + p, u[c]);
+    }
+}
+
+template <typename O, int V, bool kInter>
+__device__ __forceinline__ void store_pixels(O* __restrict__ dst, int64_t pixels, int64_t p, const O (&res)[3][V]) {
+    if constexpr (kInter) {
+        O flat[3][V];
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) flat[(3 * i + c) / V][(3 * i + c) % V] = res[c][i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) store_pack_stream<O, V>(dst + 3 * p + k * V, flat[k]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) store_pack_stream<O, V>(dst + c * pixels + p, res[c]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void load_od_scalar(const T* __restrict__ images, const Geometry& g, int64_t tile, int64_t p, float od[3]) {
+    const T* base = images + tile * 3 * g.pixels + (g.interleaved ? 3 * p : p);
+    const int64_t step = g.interleaved ? 1 : g.pixels;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(raw_value<T>(base[c * step]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -745,7 +783,7 @@ template <int TPB> struct StatsScratch {
     double red[TPB / kWave][kPartial];
 };
 
-template <typename T, int V, int TPB>
+template <typename T, int V, int TPB, bool kInter>
 __device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh) {
     const int64_t p_begin = (int64_t)chunk_id * kChunk;
     const int64_t p_end = min(p_begin + (int64_t)kChunk, g.pixels);
@@ -774,8 +812,7 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
         const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
         for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
             float u[3][V];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
+            load_pixels<T, V, kInter>(img, g.pixels, p, u);
             // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
             // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
             const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset(j, shift);
@@ -879,7 +916,7 @@ __device__ __forceinline__ void flush_queue(const uint32_t* queue, uint32_t n, u
     }
 }
 
-template <typename T, int V, bool kConc, int TPB>
+template <typename T, int V, bool kConc, int TPB, bool kInter>
 __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, BracketScratch<TPB>* sh) {
     const int group = g.pooled ? 0 : (int)tile;
     GroupState& st = ws.state[group];
@@ -900,8 +937,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 #pragma unroll
         for (int i = 0; i < V; ++i) next[c][i] = 0.0f;
     if (base + mine < p_end) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + base + mine, next[c]);
+        load_pixels<T, V, kInter>(img, g.pixels, base + mine, next);
     }
     StageRecord rec;
     load_record(&st.rec[kConc ? 1 : 0], rec);
@@ -929,8 +965,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             for (int i = 0; i < V; ++i) u[c][i] = next[c][i];
         const int64_t p_next = base + (int64_t)TPB * V + mine;
         if (p_next < p_end) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p_next, next[c]);
+            load_pixels<T, V, kInter>(img, g.pixels, p_next, next);
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -1008,7 +1043,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 // ------------------------------------------------------------------------------------------------
 // streaming stage S4: concentrations -> rescale -> reconstruct -> clamp -> cast  (torch_backend.py:452-461,560)
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename O, int V, bool kUnit, int TPB>
+template <typename T, typename O, int V, bool kUnit, int TPB, bool kInter>
 __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
                                  const float* __restrict__ stain_matrix) {
     const int64_t p_begin = (int64_t)chunk_id * kChunk;
@@ -1046,8 +1081,7 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
 
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
         float u[3][V];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
+        load_pixels<T, V, kInter>(img, g.pixels, p, u);
         O res[3][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -1074,8 +1108,7 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
                 }
             }
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) store_pack_stream<O, V>(dst + c * g.pixels + p, res[c]);
+        store_pixels<O, V, kInter>(dst, g.pixels, p, res);
     }
 }
 
@@ -1105,7 +1138,7 @@ __device__ void all_pixel_moments(const T* __restrict__ images, const Geometry& 
         int64_t tile, p;
         gp.locate(i, tile, p);
         float od[3];
-        load_od_scalar<T>(images, g.pixels, tile, p, od);
+        load_od_scalar<T>(images, g, tile, p, od);
         const double x = od[0], y = od[1], z = od[2];
         acc[0] += 1.0; acc[1] += x; acc[2] += y; acc[3] += z;
         acc[4] += x * x; acc[5] += x * y; acc[6] += x * z; acc[7] += y * y; acc[8] += y * z; acc[9] += z * z;
@@ -1235,7 +1268,7 @@ __device__ uint32_t select_whole_group(const T* __restrict__ images, const Geome
                                    int64_t tile, p;
                                    gp.locate((int64_t)i, tile, p);
                                    float od[3];
-                                   load_od_scalar<T>(images, g.pixels, tile, p, od);
+                                   load_od_scalar<T>(images, g, tile, p, od);
                                    if (!od_selected(od, use_all)) return false;
                                    if (slot < 2) {
                                        k = angle_key(od, coef);
@@ -1505,21 +1538,21 @@ __device__ void scale_stage(const T* __restrict__ images, const Geometry& g, con
 // ------------------------------------------------------------------------------------------------
 // kernels, one launch per stage (pooled fit; also the transform path when STAINX_HIP_PERSISTENT=0)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int V>
+template <typename T, int V, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ StatsScratch<kStreamThreads> sh;
-    stats_item<T, V, kStreamThreads>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh);
+    stats_item<T, V, kStreamThreads, kInter>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh);
 }
 
-template <typename T, int V, bool kConc>
+template <typename T, int V, bool kConc, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ BracketScratch<kStreamThreads> sh;
-    bracket_item<T, V, kConc, kStreamThreads>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh);
+    bracket_item<T, V, kConc, kStreamThreads, kInter>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh);
 }
 
-template <typename T, typename O, int V, bool kUnit>
+template <typename T, typename O, int V, bool kUnit, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __restrict__ images, O* __restrict__ out, Geometry g, Workspace ws, const float* __restrict__ stain_matrix) {
-    reconstruct_item<T, O, V, kUnit, kStreamThreads>(images, out, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, stain_matrix);
+    reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, stain_matrix);
 }
 
 
@@ -1601,8 +1634,7 @@ __global__ __launch_bounds__(kStreamThreads) void dfit_histogram_kernel(const T*
     const uint32_t pa = st->prefix[s0], ma = st->mask[s0], pb = st->prefix[s0 + 1], mb = st->mask[s0 + 1];
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
         float u[3][V];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * g.pixels + p, u[c]);
+        load_pixels<T, V, false>(img, g.pixels, p, u);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float od[3];
@@ -1700,27 +1732,27 @@ static void set_sampling(Geometry& g) {
     g.cap = cap_for(count);
 }
 
-template <typename T, int V>
+template <typename T, int V, bool kInter = false>
 static int run_estimate(const T* images, const Geometry& g, const Workspace& ws, int n_groups, int allow_fallback, const float* tmc, float* he_out, float* max_c_out, hipStream_t stream) {
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
-    hipLaunchKernelGGL((stats_kernel<T, V>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL((stats_kernel<T, V, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((plane_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws, allow_fallback);
-    hipLaunchKernelGGL((bracket_kernel<T, V, false>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL((bracket_kernel<T, V, false, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((stain_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws);
-    hipLaunchKernelGGL((bracket_kernel<T, V, true>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL((bracket_kernel<T, V, true, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((scale_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws, tmc, he_out, max_c_out);
     return check_launch("macenko estimate");
 }
 
-template <typename T, typename O, int V>
+template <typename T, typename O, int V, bool kInter = false>
 static int run_transform(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
     const unsigned items = (unsigned)(g.n_tiles * g.blocks_per_tile);
-    int rc = run_estimate<T, V>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
+    int rc = run_estimate<T, V, kInter>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
     if (rc != SX_OK) return rc;
     if (unit)
-        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, true>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
+        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, true, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
     else
-        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, false>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
+        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, false, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
     return check_launch("macenko reconstruct");
 }
 
@@ -1734,6 +1766,16 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     g.vec = vec ? 1 : 0;
     set_sampling(g);
     const T* in = static_cast<const T*>(images);
+    if (g.interleaved) {      // (N,H,W,3): its own instantiations, so the planar kernels carry no trace of it
+        if constexpr (sizeof(T) == 1) {
+            if (u8_unit) {
+                return vec ? run_transform<T, float, W, true>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream)
+                           : run_transform<T, float, 1, true>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream);
+            }
+        }
+        return vec ? run_transform<T, T, W, true>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream)
+                   : run_transform<T, T, 1, true>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream);
+    }
     if constexpr (sizeof(T) == 1) {
         if (u8_unit) {
             return vec ? run_transform<T, float, W>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream)
@@ -1814,7 +1856,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -1832,7 +1874,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -1859,7 +1901,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -1881,7 +1923,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {

@@ -249,3 +249,26 @@ def test_crowded_bin_path_is_exact(dev):
     want, params = so.macenko_transform(blocky.numpy(), ref_he, ref_mc, return_params=True)
     assert np.abs(out.cpu().numpy().astype(int) - want.astype(int)).max() <= 1
     np.testing.assert_allclose(p["max_c"][0].numpy(), params[0]["max_c"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", ["u8", "f32", "bf16"])
+def test_channels_last_layout_is_the_same_transform(dev, dtype):
+    """(N,H,W,3) in -> (N,H,W,3) out: the same pixels, the same arithmetic, another address pattern.
+    The per-tile parameters must be identical and the output bit-equal to the planar call (also for a size where the
+    16-byte packs do not apply), with and without the fused /255."""
+    be = _backend(dev)
+    he, max_c = be.compute_reference_stain_matrix(synth.reference_tile(96, 96).to(dev))
+    for h, w in ((96, 128), (33, 47)):
+        x = synth.as_dtype(synth.he_batch(3, h, w, seed0=4200), TORCH_DTYPES[dtype]).to(dev)
+        x_last = x.permute(0, 2, 3, 1).contiguous()
+        for unit in (False, True):
+            want = be.transform(x, he, max_c, normalize_to_0_1=unit)
+            p_planar = be.tile_params(3)
+            got = be.transform(x_last, he, max_c, normalize_to_0_1=unit, channels_last=True)
+            p_last = be.tile_params(3)
+            assert got.shape == x_last.shape and got.dtype == want.dtype
+            assert torch.equal(got.permute(0, 3, 1, 2), want), f"{dtype} {h}x{w} unit={unit}"
+            for key in ("he", "max_c", "n_kept", "cov"):
+                assert torch.equal(p_planar[key], p_last[key]), key
+    with pytest.raises(ValueError, match="NHWC"):
+        be.transform(x, he, max_c, channels_last=True)

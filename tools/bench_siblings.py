@@ -67,3 +67,11 @@ mk = Macenko(device=dev).fit(synth.reference_tile(512, 512).to(dev))
 for name, dt, bpp in (("u8", torch.uint8, 6), ("bf16", torch.bfloat16, 12), ("f16", torch.float16, 12), ("f32", torch.float32, 24)):
     xin = synth.as_dtype(u8, dt).to(dev)
     report(f"Macenko.transform 64x3x512x512 {name}", 64 * 512 * 512, bpp, *timed(lambda: mk.transform(xin)))
+
+# the same tiles as the decoder hands them over: (N,H,W,3) uint8, layout kept on the way out (C flag SX_MACENKO_CHANNELS_LAST)
+from stainx_amd.backends.torch_hip_backend import MacenkoHIP  # noqa: E402
+
+be = MacenkoHIP(dev)
+he, max_c = be.compute_reference_stain_matrix(synth.reference_tile(512, 512).to(dev))
+x_last = u8.to(dev).permute(0, 2, 3, 1).contiguous()
+report("Macenko.transform 64x512x512x3 u8 (channels last)", 64 * 512 * 512, 6, *timed(lambda: be.transform(x_last, he, max_c, channels_last=True)))
