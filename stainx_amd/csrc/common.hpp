@@ -131,12 +131,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
     return v;   // lane 0 holds the sum
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-    return v;
-}
-
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
 // ---- wave64 scans / reductions on the DPP path -----------------------------------------------------

@@ -4,8 +4,9 @@
 // rendeirolab/stainx (src/stainx/backends/torch_backend.py:399-560).  How it computes it is this
 // library's own design:
 //
-//   * four streaming stages over the pixels (planar NCHW, 16-byte loads per lane, 256-thread workgroups,
-//     8192 pixels per work item) separated by three small per-tile stages:
+//   * four streaming stages over the pixels (planar NCHW or interleaved NHWC, 16-byte loads per lane, 256-thread
+//     workgroups, 16384 pixels per work item, every wave on its own inside the pixel loop) separated by three small
+//     per-tile stages (one 1024-thread workgroup per tile, everything they need fetched in one batch of loads):
 //        S1 moments -> [plane] -> S2 angle pass -> [stain] -> S3 concentration pass -> [scale] -> S4 reconstruct
 //   * the four nearest-rank order statistics per tile (phi@1%, phi@99%, C0@99%, C1@99%;
 //     torch_backend.py:363-365) are EXACT but never sort: a 4096-pixel strided sample of the tile (its
@@ -36,7 +37,6 @@ constexpr int kSlots = 4;              // 0: phi@1  1: phi@99  2: C0@99  3: C1@9
 constexpr int kMoments = 20;           // [cnt,sx,sy,sz,xx,xy,xz,yy,yz,zz] of the pixels kept by the OD filter, then of all pixels
 constexpr int kPartial = 10;           // what S1 accumulates per work item: the kept set only (the all-pixel set is a rare fallback)
 constexpr int kShortList = 512;        // keys of one histogram bin gathered for rank counting
-constexpr int kPhasePixels = 4096;     // pixels between two flushes of the LDS candidate queues
 constexpr int kGroupThreads = 1024;    // per-tile stages: one workgroup per group, as their own launch
 constexpr int kKeys = kSample / kGroupThreads;   // sample keys a thread of a per-tile stage holds in registers
 constexpr int kPrefetchHist = 8;       // work-item histograms a thread fetches up front (2 threads per bin: 32 work items = one 512x512 tile)
@@ -47,7 +47,6 @@ constexpr float kBeta = 0.15f;         // torch_backend.py:542
 constexpr float kIo = 240.0f;          // torch_backend.py:541
 constexpr float kLn2 = 0.693147180559945309f;
 constexpr float kLnIo = 5.48063892334199f;       // ln 240
-constexpr float kLog2e = 1.44269504088896341f;
 
 // What a streaming stage needs to know about its tile; written once per call by the per-tile stage before
 // it (one record per stage, each on its own 128-byte line).
@@ -1536,7 +1535,7 @@ __device__ void scale_stage(const T* __restrict__ images, const Geometry& g, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// kernels, one launch per stage (pooled fit; also the transform path when STAINX_HIP_PERSISTENT=0)
+// kernels, one launch per stage
 // ------------------------------------------------------------------------------------------------
 template <typename T, int V, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
