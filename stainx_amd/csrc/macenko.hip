@@ -86,6 +86,21 @@ struct Geometry {
     int sample_stride, sample_count;   // sample j = pixel j*stride of the group, j < count
     uint32_t cap;                 // candidate keys per selection slot
     int interleaved;              // 1: tiles are (H,W,3) -- the three values of a pixel side by side -- instead of three planes
+    int spread;                   // 1: pooled group of several tiles; candidates, counters and histograms stay per tile (PoolState)
+};
+
+// Pooled fit over several tiles ("spread" mode): the streaming stages keep candidates, counters and histograms per
+// tile exactly as the transform does (no counter shared by 4096 waves); between them a pair of small many-workgroup
+// kernels adds the tiles up and moves the few candidates of the wanted histogram bin here, where the one workgroup
+// of the group stage finishes the selection.
+constexpr int kCompact = 32768;        // candidates of the picked bin, per slot, over all tiles
+struct alignas(256) PoolState {
+    uint32_t hist[2][2][256];          // [stage][slot][bin]: sum of the work items' histograms over all tiles
+    uint32_t below[kSlots], ncand[kSlots];
+    uint32_t compact_n[kSlots];
+    uint32_t rank_in_bin[kSlots], range[kSlots][2];
+    uint32_t ok[kSlots], overflow;     // overflow bit s: a tile's candidate buffer overflowed in slot s
+    uint32_t compact[kSlots][kCompact];
 };
 
 struct Workspace {
@@ -94,6 +109,7 @@ struct Workspace {
     uint32_t* cand;               // [groups][kSlots][cap]
     uint32_t* block_hist;         // [n_tiles*blocks_per_tile][2][256] bracket-relative histograms of a stage's candidates
     float* sample_od;             // [groups][3][kSample] optical density of the strided sample
+    struct PoolState* pool;       // pooled fit over several tiles: group-level sums and the compacted candidates
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -119,6 +135,7 @@ static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
     total += align_up(sizeof(uint32_t) * cand_words(n_tiles, pixels), 256);
     total += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     total += align_up(sizeof(float) * 3 * kSample * n, 256);
+    total += align_up(sizeof(PoolState), 256);
     return total;
 }
 
@@ -135,6 +152,8 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     w.block_hist = reinterpret_cast<uint32_t*>(p);
     p += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     w.sample_od = reinterpret_cast<float*>(p);
+    p += align_up(sizeof(float) * 3 * kSample * n, 256);
+    w.pool = reinterpret_cast<PoolState*>(p);
     return w;
 }
 
@@ -947,7 +966,8 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
     // the OD filter as one comparison: min(OD) >= threshold, with threshold -inf when every pixel is selected
     const float threshold = (kConc || rec.use_all != 0) ? -__builtin_huge_valf() : kBeta;
     const uint32_t lo_a = rec.lo[0], hi_a = rec.hi[0], lo_b = rec.lo[1], hi_b = rec.hi[1];
-    uint32_t* cand_a = ws.cand + ((size_t)group * kSlots + s0) * g.cap;
+    GroupState& store = ws.state[g.spread ? (int)tile : group];      // where this tile's candidates and counters live
+    uint32_t* cand_a = ws.cand + ((size_t)(g.spread ? (int)tile : group) * kSlots + s0) * g.cap;
     uint32_t* cand_b = cand_a + g.cap;
     uint32_t* queue_a = sh->keys[wave][0];
     uint32_t* queue_b = sh->keys[wave][1];
@@ -995,11 +1015,11 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             n_b += (uint32_t)__popcll(m_b);
             if ((i + 1) % kCheck == 0) {      // the next kCheck pixels add at most kCheck * 64 keys
                 if (n_a > (uint32_t)(kQueue - kCheck * kWave)) {
-                    flush_queue(queue_a, n_a, &st.ncand[s0], cand_a, g.cap, sh->hist[0], rec.bin_origin[0], rec.bin_scale[0]);
+                    flush_queue(queue_a, n_a, &store.ncand[s0], cand_a, g.cap, sh->hist[0], rec.bin_origin[0], rec.bin_scale[0]);
                     n_a = 0;
                 }
                 if (n_b > (uint32_t)(kQueue - kCheck * kWave)) {
-                    flush_queue(queue_b, n_b, &st.ncand[s0 + 1], cand_b, g.cap, sh->hist[1], rec.bin_origin[1], rec.bin_scale[1]);
+                    flush_queue(queue_b, n_b, &store.ncand[s0 + 1], cand_b, g.cap, sh->hist[1], rec.bin_origin[1], rec.bin_scale[1]);
                     n_b = 0;
                 }
             }
@@ -1008,8 +1028,8 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
     {   // the wave's last flush: both reservations are requested before either is waited for
         uint32_t base_a = 0, base_b = 0;
         if (lane_id() == 0) {
-            if (n_a) base_a = atomicAdd(&st.ncand[s0], n_a);
-            if (n_b) base_b = atomicAdd(&st.ncand[s0 + 1], n_b);
+            if (n_a) base_a = atomicAdd(&store.ncand[s0], n_a);
+            if (n_b) base_b = atomicAdd(&store.ncand[s0 + 1], n_b);
         }
         base_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_a);
         base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_b);
@@ -1032,7 +1052,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
     __syncthreads();
     if (threadIdx.x < 2) {
         const uint32_t sum = sh->below[threadIdx.x];
-        if (sum) atomicAdd(&st.below[s0 + threadIdx.x], sum);
+        if (sum) atomicAdd(&store.below[s0 + threadIdx.x], sum);
     }
     // the work item's histograms are stored -- not added -- so the per-tile stage reads them without a reset
     uint32_t* hist_out = ws.block_hist + (size_t)item * 512;
@@ -1215,6 +1235,14 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
             put(&st.below[s], 0u);
             put(&st.ncand[s], 0u);
         }
+    }
+    if (g.spread) {      // every tile's counters and the group-level sums start from zero
+        for (int64_t i = threadIdx.x; i < g.n_tiles * kSlots; i += blockDim.x) {
+            put(&ws.state[i / kSlots].below[i % kSlots], 0u);
+            put(&ws.state[i / kSlots].ncand[i % kSlots], 0u);
+        }
+        uint32_t* pool_words = reinterpret_cast<uint32_t*>(ws.pool);
+        for (int i = threadIdx.x; i < (int)(offsetof(PoolState, compact) / sizeof(uint32_t)); i += blockDim.x) put(&pool_words[i], 0u);
     }
     __syncthreads();
     SX_STAMP(st, 2);
@@ -1417,16 +1445,152 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// pooled fit over several tiles: the two many-workgroup kernels between a streaming stage and the group stage
+// ------------------------------------------------------------------------------------------------
+// (1) one workgroup of 512 threads per tile adds the tile's work-item histograms and counters into the PoolState
+__global__ __launch_bounds__(512) void pool_reduce_kernel(Geometry g, Workspace ws, int stage) {
+    const int tile = blockIdx.x;
+    const uint32_t* src = ws.block_hist + (size_t)tile * g.blocks_per_tile * 512 + threadIdx.x;
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (int r = 0; r < g.blocks_per_tile; ++r) sum += get(&src[(size_t)r * 512]);
+    if (sum) atomicAdd(&(&ws.pool->hist[stage][0][0])[threadIdx.x], sum);
+    if (threadIdx.x < 2) {
+        const int slot = 2 * stage + threadIdx.x;
+        const uint32_t n = get(&ws.state[tile].ncand[slot]), b = get(&ws.state[tile].below[slot]);
+        if (b) atomicAdd(&ws.pool->below[slot], b);
+        atomicAdd(&ws.pool->ncand[slot], min(n, g.cap));
+        if (n > g.cap) atomicOr(&ws.pool->overflow, 1u << slot);
+    }
+}
+
+// (2) one workgroup per tile: every workgroup scans the pooled histogram for the bin holding the wanted rank (the same
+// answer everywhere), then moves its tile's candidates of that bin to the compact list
+__global__ __launch_bounds__(kGroupThreads) void pool_gather_kernel(Geometry g, Workspace ws, int stage) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[2][256];
+    constexpr int kLocal = 2048;
+    __shared__ uint32_t range[2][2], live[2], local_n[2], local_base[2];
+    __shared__ uint32_t local[2][kLocal];
+    const int tile = blockIdx.x, wave = threadIdx.x / kWave;
+    if (threadIdx.x < 2) local_n[threadIdx.x] = 0;
+    const GroupState& st0 = ws.state[0];
+    const GroupState& mine = ws.state[tile];
+    PoolState* pool = ws.pool;
+    uint32_t pre[2][kPrefetchCand];      // the tile's first 8192 candidates per slot, requested before anything else
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t* cand = ws.cand + ((size_t)tile * kSlots + 2 * stage + j) * g.cap;
+#pragma unroll
+        for (int u = 0; u < kPrefetchCand; ++u) pre[j][u] = get(&cand[u * kGroupThreads + threadIdx.x]);
+    }
+    if (threadIdx.x < 512) (&hist[0][0])[threadIdx.x] = get(&(&pool->hist[stage][0][0])[threadIdx.x]);
+    __syncthreads();
+    if (wave < 2) {
+        const int slot = 2 * stage + wave;
+        const uint32_t ncand = get(&pool->ncand[slot]), below = get(&pool->below[slot]);
+        const unsigned long long rank = get(&st0.rank[slot]);
+        const bool ok = ((get(&pool->overflow) >> slot) & 1u) == 0 && rank >= below && rank - below < ncand;
+        uint32_t b = 0, rb = 0, first = 1, last = 0;
+        if (ok) {
+            scan_pick32(hist[wave], (uint32_t)(rank - below), b, rb);
+            if (lane_id() == 0) bin_key_range(b, get(&st0.rec[stage].bin_origin[wave]), get(&st0.rec[stage].bin_scale[wave]), first, last);
+        }
+        if (lane_id() == 0) {
+            range[wave][0] = first;
+            range[wave][1] = last;
+            live[wave] = ok ? 1u : 0u;
+            if (tile == 0) {
+                put(&pool->ok[slot], ok ? 1u : 0u);
+                put(&pool->rank_in_bin[slot], rb);
+                put(&pool->range[slot][0], first);
+                put(&pool->range[slot][1], last);
+            }
+        }
+    }
+    __syncthreads();
+    // matches are collected in LDS first; one reservation per workgroup and slot in the pooled list (thousands of returning
+    // atomics on one address from 64 workgroups cost 60 us)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (!live[j]) continue;
+        const int slot = 2 * stage + j;
+        const uint32_t k_first = range[j][0], k_last = range[j][1], n = min(get(&mine.ncand[slot]), g.cap);
+        const uint32_t* cand = ws.cand + ((size_t)tile * kSlots + slot) * g.cap;
+        auto keep = [&](uint32_t k) {
+            const uint32_t at = atomicAdd(&local_n[j], 1u);
+            if (at < (uint32_t)kLocal) {
+                local[j][at] = k;
+            } else {      // more than the LDS list holds (degenerate data): straight to the pooled list
+                const uint32_t g_at = atomicAdd(&pool->compact_n[slot], 1u);
+                if (g_at < (uint32_t)kCompact) put(&pool->compact[slot][g_at], k);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < kPrefetchCand; ++u) {
+            const uint32_t idx = u * kGroupThreads + threadIdx.x, k = pre[j][u];
+            if (idx < n && k >= k_first && k <= k_last) keep(k);
+        }
+        for (uint32_t idx = kPrefetchCand * kGroupThreads + threadIdx.x; idx < n; idx += kGroupThreads) {
+            const uint32_t k = get(&cand[idx]);
+            if (k >= k_first && k <= k_last) keep(k);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && live[threadIdx.x]) {
+        const uint32_t m = min(local_n[threadIdx.x], (uint32_t)kLocal);
+        local_base[threadIdx.x] = m ? atomicAdd(&pool->compact_n[2 * stage + threadIdx.x], m) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (!live[j]) continue;
+        const uint32_t m = min(local_n[j], (uint32_t)kLocal), base = local_base[j];
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
+            if (base + i < (uint32_t)kCompact) put(&pool->compact[2 * stage + j][base + i], local[j][i]);
+    }
+}
+
+// (3) in the group stage: the compact list (the candidates of ONE value-linear bin over all tiles: hundreds to a few
+// thousand keys, with heavy ties when the tiles come from 8-bit data) goes to LDS and four byte-wise radix rounds over
+// it give the wanted element; a list that does not fit LDS is read from memory in every round.
+template <typename T>
+__device__ void resolve_pair_spread(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int first_slot, const float* coef, bool use_all,
+                                    uint32_t (&key_out)[2], TileScratch* sh) {
+    GroupState& st = ws.state[0];
+    const PoolState* pool = ws.pool;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int slot = first_slot + j;
+        const uint32_t n = get(&pool->compact_n[slot]), want = get(&pool->rank_in_bin[slot]);
+        const bool ok = get(&pool->ok[slot]) != 0 && n <= (uint32_t)kCompact && want < n;      // uniform
+        if (ok && n <= (uint32_t)kSample) {
+            uint32_t* keys = sh->keys[j];      // the sample-key area is free until the brackets are taken
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) keys[i] = get(&pool->compact[slot][i]);
+            key_out[j] = radix_select_stream((unsigned long long)n, (unsigned long long)want, [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return true; }, sh);
+        } else if (ok) {
+            const uint32_t* keys = pool->compact[slot];
+            if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
+            key_out[j] = radix_select_stream((unsigned long long)n, (unsigned long long)want, [keys](unsigned long long i, uint32_t& k) { k = get(&keys[i]); return true; }, sh);
+        } else {      // bracket missed or a buffer overflowed: recompute every key of the group (exact, slow)
+            if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << slot);
+            key_out[j] = select_whole_group<T>(images, g, 0, slot, get(&st.rank[slot]), coef, use_all, sh);
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-tile stage B ("stain"): angle percentiles -> HE_source -> pseudo-inverse; concentration brackets
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool kSpread = false>
 __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, TileScratch* sh) {
     GroupState& st = ws.state[group];
     const GroupPixels gp = group_pixels(g, group);
     SX_STAMP(st, 6);
     reset_scratch(sh);
     PairPrefetch pf;
-    prefetch_pair(pf, g, ws, group, 0);
+    if constexpr (!kSpread) prefetch_pair(pf, g, ws, group, 0);
     float sod[kKeys][3];
     load_sample(ws, group, g.sample_count, sod);
     float vecs[6];
@@ -1434,7 +1598,13 @@ __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, con
     for (int i = 0; i < 6; ++i) vecs[i] = get(&st.rec[0].coef[i]);
     const bool use_all = get(&st.rec[0].use_all) != 0;
     uint32_t phi_key[2];
-    resolve_pair<T>(images, g, ws, group, 0, vecs, use_all, pf, phi_key, sh);
+    if constexpr (kSpread) {
+        pf.ncand[0] = get(&ws.pool->ncand[0]);
+        pf.ncand[1] = get(&ws.pool->ncand[1]);
+        resolve_pair_spread<T>(images, g, ws, 0, vecs, use_all, phi_key, sh);
+    } else {
+        resolve_pair<T>(images, g, ws, group, 0, vecs, use_all, pf, phi_key, sh);
+    }
     SX_STAMP(st, 7);
     if (threadIdx.x == 0) {
         float he[6], pinv[6];
@@ -1498,19 +1668,25 @@ __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, con
 // ------------------------------------------------------------------------------------------------
 // per-tile stage C ("scale"): concentration percentiles -> scale factors (transform) / outputs (fit)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool kSpread = false>
 __device__ void scale_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, const float* __restrict__ target_max_conc, float* __restrict__ he_out,
                             float* __restrict__ max_c_out, TileScratch* sh) {
     GroupState& st = ws.state[group];
     SX_STAMP(st, 12);
     reset_scratch(sh);
     PairPrefetch pf;
-    prefetch_pair(pf, g, ws, group, 2);
+    if constexpr (!kSpread) prefetch_pair(pf, g, ws, group, 2);
     float pinv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) pinv[i] = get(&st.rec[1].coef[i]);
     uint32_t c_key[2];
-    resolve_pair<T>(images, g, ws, group, 2, pinv, true, pf, c_key, sh);
+    if constexpr (kSpread) {
+        pf.ncand[0] = get(&ws.pool->ncand[2]);
+        pf.ncand[1] = get(&ws.pool->ncand[3]);
+        resolve_pair_spread<T>(images, g, ws, 2, pinv, true, c_key, sh);
+    } else {
+        resolve_pair<T>(images, g, ws, group, 2, pinv, true, pf, c_key, sh);
+    }
     SX_STAMP(st, 13);
     if (threadIdx.x == 0) {
         const float m0 = key_float(c_key[0]), m1 = key_float(c_key[1]);
@@ -1561,16 +1737,16 @@ __global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restric
     plane_stage<T>(images, g, ws, blockIdx.x, allow_fallback, &sh);
 }
 
-template <typename T>
+template <typename T, bool kSpread = false>
 __global__ __launch_bounds__(kGroupThreads) void stain_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ TileScratch sh;
-    stain_stage<T>(images, g, ws, blockIdx.x, &sh);
+    stain_stage<T, kSpread>(images, g, ws, blockIdx.x, &sh);
 }
 
-template <typename T>
+template <typename T, bool kSpread = false>
 __global__ __launch_bounds__(kGroupThreads) void scale_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc, float* __restrict__ he_out, float* __restrict__ max_c_out) {
     __shared__ TileScratch sh;
-    scale_stage<T>(images, g, ws, blockIdx.x, target_max_conc, he_out, max_c_out, &sh);
+    scale_stage<T, kSpread>(images, g, ws, blockIdx.x, target_max_conc, he_out, max_c_out, &sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1728,7 +1904,8 @@ static void set_sampling(Geometry& g) {
     while ((count + stride - 1) / stride > kSample) stride *= 2;
     g.sample_stride = (int)stride;
     g.sample_count = (int)std::min<int64_t>(kSample, (count + stride - 1) / stride);
-    g.cap = cap_for(count);
+    g.spread = (g.pooled && g.n_tiles > 1) ? 1 : 0;
+    g.cap = cap_for(g.spread ? g.pixels : count);
 }
 
 template <typename T, int V, bool kInter = false>
@@ -1737,9 +1914,21 @@ static int run_estimate(const T* images, const Geometry& g, const Workspace& ws,
     hipLaunchKernelGGL((stats_kernel<T, V, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((plane_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws, allow_fallback);
     hipLaunchKernelGGL((bracket_kernel<T, V, false, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
-    hipLaunchKernelGGL((stain_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws);
+    if (g.spread) {
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)g.n_tiles), dim3(512), 0, stream, g, ws, 0);
+        hipLaunchKernelGGL(pool_gather_kernel, dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, g, ws, 0);
+        hipLaunchKernelGGL((stain_kernel<T, true>), dim3(1), dim3(kGroupThreads), 0, stream, images, g, ws);
+    } else {
+        hipLaunchKernelGGL((stain_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws);
+    }
     hipLaunchKernelGGL((bracket_kernel<T, V, true, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
-    hipLaunchKernelGGL((scale_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws, tmc, he_out, max_c_out);
+    if (g.spread) {
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)g.n_tiles), dim3(512), 0, stream, g, ws, 1);
+        hipLaunchKernelGGL(pool_gather_kernel, dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, g, ws, 1);
+        hipLaunchKernelGGL((scale_kernel<T, true>), dim3(1), dim3(kGroupThreads), 0, stream, images, g, ws, tmc, he_out, max_c_out);
+    } else {
+        hipLaunchKernelGGL((scale_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws, tmc, he_out, max_c_out);
+    }
     return check_launch("macenko estimate");
 }
 
@@ -1855,7 +2044,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -1873,7 +2062,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -1900,7 +2089,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -1922,7 +2111,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
