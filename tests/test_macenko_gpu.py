@@ -272,3 +272,36 @@ def test_channels_last_layout_is_the_same_transform(dev, dtype):
                 assert torch.equal(p_planar[key], p_last[key]), key
     with pytest.raises(ValueError, match="NHWC"):
         be.transform(x, he, max_c, channels_last=True)
+
+
+def test_pooled_fit_paths(dev):
+    """The pooled fit over several tiles (candidates kept per tile, reduce/gather kernels, radix finish): an odd size
+    that takes the scalar loads, a batch of 8-bit tiles (heavy ties), and a batch whose few distinct pixels overflow
+    the per-tile candidate buffers so that the whole-group select must run -- all against the oracle's pooled fit."""
+    be = _backend(dev)
+    # (a) odd size, float tiles
+    x = synth.as_dtype(synth.he_batch(5, 33, 47, seed0=910, scale_step=0.05), torch.float32)
+    he, mc = be.compute_reference_stain_matrix(x.to(dev))
+    want_he, want_mc = so.macenko_fit(x.numpy(), signs="positive_sum")
+    np.testing.assert_allclose(he.cpu().numpy(), want_he, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(mc.cpu().numpy(), want_mc, rtol=1e-4, atol=0)
+    # (b) 8-bit tiles, bigger batch: ties everywhere, the compact list is long
+    u8 = synth.he_batch(12, 256, 256, seed0=77)
+    he, mc = be.compute_reference_stain_matrix(u8.to(dev))
+    p = be.tile_params(1)
+    assert int(p["fell_back"][0]) & 0xF == 0, "the bracket path is expected to hold on ordinary tiles"
+    want_he, want_mc = so.macenko_fit(u8.numpy(), signs="positive_sum")
+    np.testing.assert_allclose(he.cpu().numpy(), want_he, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(mc.cpu().numpy(), want_mc, rtol=1e-4, atol=0)
+    # (c) 8 distinct pixels per tile: every bracket holds whole tie groups larger than a tile's candidate buffer
+    tile = synth.he_batch(2, 1024, 1024, seed0=55)
+    blocky = tile[:, :, ::512, ::256].repeat_interleave(512, dim=2).repeat_interleave(256, dim=3).contiguous()
+    he, mc = be.compute_reference_stain_matrix(blocky.to(dev))
+    p = be.tile_params(1)
+    assert int(p["fell_back"][0]) & 0xF == 0xF, "expected the whole-group select for all four slots"
+    want_he, want_mc = so.macenko_fit(blocky.numpy(), signs="positive_sum")
+    # 16 distinct OD vectors: the two small eigenvalues of the covariance are nearly equal, so the middle eigenvector (and
+    # with it HE) moves by 1e-3 with the last bits of the covariance (fp32 two-pass in the reference, fp64 here); the
+    # order statistics themselves are exact
+    np.testing.assert_allclose(he.cpu().numpy(), want_he, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(mc.cpu().numpy(), want_mc, rtol=1e-4, atol=0)
