@@ -744,7 +744,7 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
     bool crowded = false;
 #pragma unroll
     for (int q = 0; q < 4; ++q) crowded = crowded || sh->count_s[q] > (uint32_t)kShortList;
-    if (!crowded) {
+    if (__builtin_expect(!crowded, 1)) {
         // the four short lists are ranked side by side, a quarter of the workgroup each
         const uint32_t per = blockDim.x / 4, q = threadIdx.x / per;
         rank_pick(sh->list_s[q], sh->count_s[q], sh->rank_in_bin_s[q], threadIdx.x - q * per, per, &sh->result_s[q]);
@@ -1207,7 +1207,7 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
         if (threadIdx.x > kPartial && threadIdx.x < kMoments) sh->mom[threadIdx.x] = 0.0;   // the sums only matter in the fallback below
     }
     __syncthreads();
-    if (allow_fallback && sh->mom[0] < 3.0) all_pixel_moments<T>(images, g, group, sh);     // uniform, rare (blank tiles)
+    if (__builtin_expect(allow_fallback && sh->mom[0] < 3.0, 0)) all_pixel_moments<T>(images, g, group, sh);     // uniform, rare (blank tiles)
     __syncthreads();
     SX_STAMP(st, 1);
     if (threadIdx.x == 0) {
@@ -1431,7 +1431,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int slot = first_slot + j;
-        if (ok[j] && sh->count_c[j] <= (uint32_t)kShortList) {
+        if (__builtin_expect(ok[j] && sh->count_c[j] <= (uint32_t)kShortList, 1)) {
             key_out[j] = sh->result_c[j];
         } else if (ok[j]) {      // crowded bin: radix rounds over the candidates
             const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * g.cap;
