@@ -130,6 +130,7 @@ def main() -> None:
     elapsed = float(t.item())
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     dev_ms = sum(step_ms) / len(step_ms)
+    dev_std = (sum((v - dev_ms) ** 2 for v in step_ms) / max(len(step_ms) - 1, 1)) ** 0.5
 
     if rank == 0:
         pixels = TILES * HEIGHT * WIDTH
@@ -146,9 +147,9 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(), "algorithmic_bytes_per_launch": pixels * BYTES_PER_PIXEL,
                          "kernel": "all 7 launches of one sx_macenko_transform call (stats, plane, bracket<phi>, stain, bracket<conc>, scale, reconstruct)",
-                         "device_ms_per_call": round(dev_ms, 4), "device_ms_min": round(min(step_ms), 4),
+                         "device_ms_per_call": round(dev_ms, 4), "device_ms_std": round(dev_std, 4), "device_ms_min": round(min(step_ms), 4),
                          "dominant_kernel": {"name": "reconstruct_kernel", "algorithmic_bytes": pixels * BYTES_PER_PIXEL,
-                                             "note": "the only launch that moves the full 24 B/px; its rocprofv3 average is in profiles/r01_*_kernel_stats.csv"}},
+                                             "note": "the only launch that moves the full 24 B/px; its rocprofv3 average is in profiles/r01_final_macenko_cfg2_kernel_stats.csv"}},
         }
         if world == 1 and not args.no_cpu:
             he = norm._stain_matrix.cpu().numpy()

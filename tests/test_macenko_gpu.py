@@ -305,3 +305,21 @@ def test_pooled_fit_paths(dev):
     # order statistics themselves are exact
     np.testing.assert_allclose(he.cpu().numpy(), want_he, rtol=0, atol=5e-3)
     np.testing.assert_allclose(mc.cpu().numpy(), want_mc, rtol=1e-4, atol=0)
+
+
+def test_big_batch_equals_its_pieces(dev):
+    """A batch larger than the 256 MB Infinity Cache: tiles are independent, so the result must be bit-equal to
+    transforming the pieces separately, and the per-tile parameters of all tiles must match too."""
+    be = _backend(dev)
+    he, max_c = be.compute_reference_stain_matrix(synth.reference_tile(128, 128).to(dev))
+    base = synth.as_dtype(synth.he_batch(8, 512, 512, seed0=3100), torch.float32).to(dev)
+    x = base.repeat(12, 1, 1, 1).contiguous()                     # 96 tiles, 302 MB
+    x[5] = base[3] * 0.9                                           # make one tile of the first part and one of the last differ
+    x[90] = base[6] * 0.8
+    out = be.transform(x, he, max_c)
+    params = be.tile_params(96)
+    for lo, hi in ((0, 48), (48, 96)):
+        part = be.transform(x[lo:hi].contiguous(), he, max_c)
+        assert torch.equal(out[lo:hi], part)
+        p = be.tile_params(hi - lo)
+        assert torch.equal(params["he"][lo:hi], p["he"]) and torch.equal(params["max_c"][lo:hi], p["max_c"])
