@@ -347,13 +347,14 @@ __device__ void plane_from_moments(const double* mom, bool allow_fallback, doubl
     const double* a = use_all ? mom + 10 : mom;
     const double cnt = a[0];
     if (cnt > 1.0) {
-        const double m0 = a[1] / cnt, m1 = a[2] / cnt, m2 = a[3] / cnt, d = cnt - 1.0;
-        cov[0] = (a[4] - a[1] * m0) / d;
-        cov[1] = cov[3] = (a[5] - a[1] * m1) / d;
-        cov[2] = cov[6] = (a[6] - a[1] * m2) / d;
-        cov[4] = (a[7] - a[2] * m1) / d;
-        cov[5] = cov[7] = (a[8] - a[2] * m2) / d;
-        cov[8] = (a[9] - a[3] * m2) / d;
+        const double inv_n = 1.0 / cnt, inv_d = 1.0 / (cnt - 1.0);      // two fp64 divisions (software, ~40 instructions each) instead of nine
+        const double m0 = a[1] * inv_n, m1 = a[2] * inv_n, m2 = a[3] * inv_n;
+        cov[0] = (a[4] - a[1] * m0) * inv_d;
+        cov[1] = cov[3] = (a[5] - a[1] * m1) * inv_d;
+        cov[2] = cov[6] = (a[6] - a[1] * m2) * inv_d;
+        cov[4] = (a[7] - a[2] * m1) * inv_d;
+        cov[5] = cov[7] = (a[8] - a[2] * m2) * inv_d;
+        cov[8] = (a[9] - a[3] * m2) * inv_d;
     } else {
 #pragma unroll
         for (int i = 0; i < 9; ++i) cov[i] = 0.0;
@@ -418,8 +419,13 @@ __device__ void stain_vectors_and_pinv(const float* vecs, uint32_t key_lo, uint3
     const double a = (double)he[0] * he[0] + (double)he[2] * he[2] + (double)he[4] * he[4];
     const double b = (double)he[0] * he[1] + (double)he[2] * he[3] + (double)he[4] * he[5];
     const double d = (double)he[1] * he[1] + (double)he[3] * he[3] + (double)he[5] * he[5];
+    // (hardware v_rcp_f64 / v_rsq_f64 seeds + two Newton steps each, ~1e-15 relative: the software fp64 division and square
+    // root cost ~40 instructions apiece on the one lane that runs this)
+    auto fast_rcp = [](double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); return r * (2.0 - x * r); };
+    auto fast_rsqrt = [](double x) { double r = __builtin_amdgcn_rsq(x); r = r * (1.5 - 0.5 * x * r * r); return r * (1.5 - 0.5 * x * r * r); };
     const double tr = a + d, df = a - d;
-    const double disc = sqrt(df * df + 4.0 * b * b);
+    const double disc2 = df * df + 4.0 * b * b;
+    const double disc = disc2 > 0.0 ? disc2 * fast_rsqrt(disc2) : 0.0;
     const double l1 = 0.5 * (tr + disc), l2 = 0.5 * (tr - disc);
     double e1x, e1y;                                   // unit eigenvector of l1
     if (fabs(b) > 0.0) {
@@ -432,13 +438,13 @@ __device__ void stain_vectors_and_pinv(const float* vecs, uint32_t key_lo, uint3
         e1x = 0.0;
         e1y = 1.0;
     }
-    const double nrm = sqrt(e1x * e1x + e1y * e1y);
-    e1x /= nrm;
-    e1y /= nrm;
+    const double inv_nrm = fast_rsqrt(e1x * e1x + e1y * e1y);
+    e1x *= inv_nrm;
+    e1y *= inv_nrm;
     const double e2x = -e1y, e2y = e1x;
     const double rc = 3.0 * 1.1920928955078125e-07;
-    const double i1 = l1 > 0.0 ? 1.0 / l1 : 0.0;
-    const double i2 = (l2 > 0.0 && sqrt(l2) > rc * sqrt(l1)) ? 1.0 / l2 : 0.0;
+    const double i1 = l1 > 0.0 ? fast_rcp(l1) : 0.0;
+    const double i2 = (l2 > 0.0 && l2 > rc * rc * l1) ? fast_rcp(l2) : 0.0;      // sigma_2 > rc * sigma_1, squared
     // (HE^T HE)^+ = i1 e1 e1^T + i2 e2 e2^T
     const double g00 = i1 * e1x * e1x + i2 * e2x * e2x, g01 = i1 * e1x * e1y + i2 * e2x * e2y, g11 = i1 * e1y * e1y + i2 * e2y * e2y;
 #pragma unroll
@@ -540,7 +546,9 @@ __device__ __forceinline__ uint32_t bin_of(uint32_t key, double origin, double s
 __device__ __forceinline__ double bin_origin_for(uint32_t lo) { return (double)key_float(lo); }
 __device__ __forceinline__ double bin_scale_for(uint32_t lo, uint32_t hi) {
     const double span = (double)key_float(hi) - (double)key_float(lo);
-    return (span > 0.0 && span < 1e300) ? 256.0 / span : 0.0;
+    // bare v_rcp_f64 instead of a software division: any value works as long as everyone uses the SAME one -- inside
+    // sample_brackets all threads evaluate this identically, for the candidates it travels in the stage record
+    return (span > 0.0 && span < 1e300) ? 256.0 * __builtin_amdgcn_rcp(span) : 0.0;
 }
 
 // The keys bin b holds, as an inclusive range [first, last] (bin_of is monotone in the key): the edge value is
@@ -558,7 +566,7 @@ __device__ __forceinline__ void bin_key_range(uint32_t b, double origin, double 
         last = b == 0 ? 0xFFFFFFFFu : 0u;
         return;
     }
-    const double inv_scale = 1.0 / scale;
+    const double inv_scale = __builtin_amdgcn_rcp(scale);      // seed only: the edges are walked to the exact boundary
     first = b == 0 ? 0u : bin_lower_edge(b, origin, scale, inv_scale);
     last = b >= 255u ? 0xFFFFFFFFu : bin_lower_edge(b + 1u, origin, scale, inv_scale) - 1u;
 }
@@ -688,17 +696,16 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
         origin[set] = bin_origin_for(set_lo);
         scale[set] = bin_scale_for(set_lo, set_hi);
     }
-    uint32_t rank[4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    // Sample rank of query q (0: low side of bracket 0, 1: its high side, 2/3: bracket 1) -- fp64 square root and divisions,
+    // so it is worked out only by the wave that scans for it, not by all sixteen.  A bracket rank beyond the sample is
+    // clamped to the sample's extreme: the bracket stays closed (an open side would gather the whole tail, ~1 % of the
+    // tile); the wanted element lying beyond all 4096 samples is a 1e-18 event and, like every bracket miss, is caught
+    // by the count check and repaired by the slow path.
+    auto rank_of = [&](int q) -> uint32_t {
         long long lo_r, hi_r;
-        bracket_ranks(m_valid, n_total, k0[s], lo_r, hi_r);
-        // a bracket rank beyond the sample is clamped to the sample's extreme: the bracket stays closed (an open side
-        // would gather the whole tail, ~1 % of the tile); the wanted element lying beyond all 4096 samples is a
-        // 1e-18 event and, like every bracket miss, is caught by the count check and repaired by the slow path
-        rank[2 * s] = (uint32_t)min(max(lo_r, 0ll), (long long)m_valid - 1);
-        rank[2 * s + 1] = (uint32_t)min(max(hi_r, 0ll), (long long)m_valid - 1);
-    }
+        bracket_ranks(m_valid, n_total, (q >> 1) ? k0[1] : k0[0], lo_r, hi_r);
+        return (uint32_t)min(max((q & 1) ? hi_r : lo_r, 0ll), (long long)m_valid - 1);
+    };
     uint32_t bin[kSets][kKeys];
 #pragma unroll
     for (int set = 0; set < kSets; ++set)
@@ -715,7 +722,7 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
     const int wave = threadIdx.x / kWave;
     if (wave < 4) {
         uint32_t b, rb;
-        scan_pick32(sh->hist_s[kSets == 2 ? (wave >> 1) : 0], rank[wave], b, rb);
+        scan_pick32(sh->hist_s[kSets == 2 ? (wave >> 1) : 0], rank_of(wave), b, rb);
         if (lane == 0) {
             sh->bin_s[wave] = b;
             sh->rank_in_bin_s[wave] = rb;
@@ -755,7 +762,7 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t* keys = sh->keys[kSets == 2 ? (q >> 1) : 0];
-            res[q] = radix_select_stream((unsigned long long)kSample, (unsigned long long)rank[q], [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return k != 0xFFFFFFFFu; }, sh);
+            res[q] = radix_select_stream((unsigned long long)kSample, (unsigned long long)rank_of(q), [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return k != 0xFFFFFFFFu; }, sh);
         }
     }
 #pragma unroll
