@@ -466,11 +466,13 @@ __device__ __forceinline__ unsigned long long nearest_rank_index(double q, unsig
 // Sample ranks bracketing the wanted rank: +-6 standard deviations of the rank a sample of m_valid keys
 // gives to the k0-th of n_total keys, plus slack.  A miss is detected later and repaired.
 __device__ __forceinline__ void bracket_ranks(int m_valid, unsigned long long n_total, unsigned long long k0, long long& lo_r, long long& hi_r) {
-    const double f = n_total > 1 ? (double)k0 / (double)(n_total - 1) : 0.0;
-    const double r = f * (double)(m_valid - 1);
-    const double sd = sqrt((double)m_valid * f * (1.0 - f));
-    lo_r = (long long)floor(r - 6.0 * sd - 3.0);
-    hi_r = (long long)ceil(r + 6.0 * sd + 3.0);
+    // fp32 with the bare hardware reciprocal / square root: the bracket is an estimate (+-6 sigma + 3 ranks of slack, a
+    // miss is detected and repaired), it only has to be the same wherever it is evaluated -- one wave per bracket side
+    const float f = n_total > 1 ? (float)k0 * __builtin_amdgcn_rcpf((float)(n_total - 1)) : 0.0f;
+    const float r = f * (float)(m_valid - 1);
+    const float sd = __builtin_amdgcn_sqrtf(fmaxf((float)m_valid * f * (1.0f - f), 0.0f));
+    lo_r = (long long)floorf(r - 6.0f * sd - 3.0f);
+    hi_r = (long long)ceilf(r + 6.0f * sd + 3.0f);
 }
 
 // One wave turns a 256-bin histogram and a rank into (bin, rank inside that bin).
