@@ -1,0 +1,64 @@
+"""CPU simulation (numpy, no GPU): how many pixels a MERGED angle + concentration pass would have to keep as concentration
+candidates, for the 4096-pixel sample the kernels use today and for a 16384-pixel one.  The test
+per pixel is the rigorous one: the range of C over the box of possible stain angles against the envelope of the sample
+brackets."""
+import sys, numpy as np, torch
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+from stainx_amd import synth
+from oracle import stain_oracle as so
+
+def nearest_rank(n, q): return int(np.rint(0.01*q*(n-1)))
+def bracket_ranks(m, n, k0):
+    f = k0/(n-1); r = f*(m-1); sd = np.sqrt(m*f*(1-f))
+    return max(int(np.floor(r-6*sd-3)),0), min(int(np.ceil(r+6*sd+3)), m-1)
+
+tiles = synth.as_dtype(synth.he_batch(6, 512, 512, seed0=1000), torch.float32).numpy()
+for ti in range(6):
+    x = tiles[ti]
+    od = so.optical_density(so.to_unit_float(x[None]))[0].reshape(3, -1).T.astype(np.float64)   # (P,3)
+    keep = od.min(1) >= 0.15
+    odk = od[keep]
+    cov = np.cov(odk.T)
+    w, v = np.linalg.eigh(cov)
+    V = v[:, [1, 2]]
+    V = V * np.sign(V.sum(0))
+    t = od @ V                     # all pixels
+    tk = t[keep]
+    theta = np.arctan2(tk[:, 1], tk[:, 0])
+    n = theta.size
+    for m in (4096, 16384):
+        rng = np.random.default_rng(ti)
+        idx = rng.choice(t.shape[0], m, replace=False)
+        samp_keep = keep[idx]
+        th_s = np.sort(np.arctan2(t[idx][samp_keep][:, 1], t[idx][samp_keep][:, 0]))
+        mv = th_s.size
+        br = []
+        for q in (1.0, 99.0):
+            lo, hi = bracket_ranks(mv, n, nearest_rank(n, q))
+            br.append((th_s[lo], th_s[hi]))
+        (a_lo, a_hi), (b_lo, b_hi) = br
+        # exact
+        ths = np.sort(theta)
+        pa, pb = ths[nearest_rank(n, 1.0)], ths[nearest_rank(n, 99.0)]
+        assert a_lo <= pa <= a_hi and b_lo <= pb <= b_hi
+        # C for all pixels at the four corners (ordering H/E ignored: use e1=phi_a, e2=phi_b)
+        th_all = np.arctan2(t[:, 1], t[:, 0]); r = np.hypot(t[:, 0], t[:, 1])
+        def C(pa_, pb_):
+            det = np.sin(pb_ - pa_)
+            return r*np.sin(pb_ - th_all)/det, r*np.sin(th_all - pa_)/det
+        corners = [C(x_, y_) for x_ in (a_lo, a_hi) for y_ in (b_lo, b_hi)]
+        P = t.shape[0]
+        fr = []
+        for k in (0, 1):
+            cmin = np.min([c[k] for c in corners], 0); cmax = np.max([c[k] for c in corners], 0)
+            # quantile bracket: from the sample at the corner that gives min / max, +-6 sigma ranks
+            s_idx = idx
+            qlo = []; qhi = []
+            for c in corners:
+                cs = np.sort(c[k][s_idx])
+                lo, hi = bracket_ranks(m, P, nearest_rank(P, 99.0))
+                qlo.append(cs[lo]); qhi.append(cs[hi])
+            Qlo, Qhi = min(qlo), max(qhi)
+            cand = (cmax >= Qlo) & (cmin <= Qhi)
+            fr.append(cand.mean())
+        print(f"tile {ti} sample {m:5d}: dphi_a {a_hi-a_lo:.4f} dphi_b {b_hi-b_lo:.4f} gap {pb-pa:.3f}  C-candidate fraction {fr[0]*100:.1f}% / {fr[1]*100:.1f}%   (phi candidates {(np.mean((theta>=a_lo)&(theta<=a_hi))+np.mean((theta>=b_lo)&(theta<=b_hi)))*100:.1f}%)")
