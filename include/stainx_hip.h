@@ -93,6 +93,41 @@ int sx_macenko_dfit_histogram(const void* images_dev, int dtype, int64_t n_tiles
 int sx_macenko_dfit_advance(void* state_dev, int stage, const unsigned long long* hist_dev, void* stream);
 int sx_macenko_dfit_result(const void* state_dev, float* he_out_dev, float* max_c_out_dev, void* stream);
 
+/* The same pooled fit across ranks on the BRACKET machinery of sx_macenko_fit: three passes over the local tiles
+ * instead of nine.  Every rank calls the steps in lockstep; the host moves four small device buffers in between
+ * (`stainx_amd/distributed.py` does it with torch.distributed):
+ *   sx_macenko_pfit_stats    local moments (10 doubles) -> all-reduce(SUM); local sample (3 x 4096 floats, the first
+ *                            sx_macenko_pfit_sample_count() columns valid) -> all-gather; every rank builds the same
+ *                            4096-column union (every world-th column of every rank)
+ *   sx_macenko_pfit_plane    global moments + n_all (pixels over all ranks) + union sample -> plane, angle brackets
+ *   sx_macenko_pfit_pass     stage 0 angle / 1 concentration: local counts and histogram (SX_PFIT_SUMS int64 values)
+ *                            -> all-reduce(SUM)
+ *   sx_macenko_pfit_gather   global sums in; local candidates of the picked bin out (2 x share keys, 2 counts; share =
+ *                            SX_PFIT_COMPACT / world) -> all-gather
+ *   sx_macenko_pfit_finish   gathered candidates [world][2][share], counts [world][2] -> exact percentiles;
+ *                            stage 0: stain vectors and concentration brackets, stage 1: HE, maxC and *status_out
+ *                            (non-zero: a bracket did not hold somewhere -- repeat with the sx_macenko_dfit_* rounds)
+ * Integer counts and an order-independent selection: every rank ends with the same bits. */
+#define SX_PFIT_SUMS 1033
+#define SX_PFIT_COMPACT 32768
+int sx_macenko_pfit_sample_count(int64_t n_tiles, int64_t height, int64_t width);
+int sx_macenko_pfit_stats(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
+                          double* moments_out_dev, float* sample_out_dev, void* workspace_dev, size_t workspace_bytes,
+                          void* stream);
+int sx_macenko_pfit_plane(const double* moments_dev, long long n_all, const float* sample_union_dev, int sample_count,
+                          int64_t n_tiles, int64_t height, int64_t width, void* workspace_dev, size_t workspace_bytes,
+                          void* stream);
+int sx_macenko_pfit_pass(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width, int stage,
+                         long long n_all, int sample_count, long long* sums_out_dev, void* workspace_dev,
+                         size_t workspace_bytes, void* stream);
+int sx_macenko_pfit_gather(const long long* sums_global_dev, int stage, long long n_all, int sample_count,
+                           int64_t n_tiles, int64_t height, int64_t width, int share, unsigned* compact_out_dev,
+                           int* counts_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int sx_macenko_pfit_finish(const unsigned* gathered_compact_dev, const int* gathered_counts_dev, int world, int share, int stage,
+                           long long n_all, int sample_count, int64_t n_tiles, int64_t height, int64_t width,
+                           float* he_out_dev, float* max_c_out_dev, int* status_out_dev, void* workspace_dev,
+                           size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- Reinhard -----------------------
  * Replaces stainx_cuda_torch.reinhard (bindings.cpp:32) with the numerics of ReinhardTorch
  * (torch_backend.py:304-355): LAB statistics pooled over the whole batch, unbiased std. */

@@ -20,6 +20,8 @@ SX_OK, SX_ERR_BAD_ARG, SX_ERR_DTYPE, SX_ERR_WORKSPACE, SX_ERR_LAUNCH = range(5)
 MACENKO_NORMALIZE_0_1 = 1
 MACENKO_CHANNELS_LAST = 2
 MACENKO_PARAM_FLOATS = 48
+PFIT_SUMS = 1033
+PFIT_COMPACT = 32768
 
 DTYPE_CODES = {torch.uint8: 0, torch.float16: 1, torch.bfloat16: 2, torch.float32: 3, torch.float64: 4}
 
@@ -40,6 +42,12 @@ SIGNATURES = {
     "sx_macenko_dfit_histogram": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _int, _vp, _vp]),
     "sx_macenko_dfit_advance": (_int, [_vp, _int, _vp, _vp]),
     "sx_macenko_dfit_result": (_int, [_vp, _vp, _vp, _vp]),
+    "sx_macenko_pfit_sample_count": (_int, [_i64, _i64, _i64]),
+    "sx_macenko_pfit_stats": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "sx_macenko_pfit_plane": (_int, [_vp, _c.c_longlong, _vp, _int, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "sx_macenko_pfit_pass": (_int, [_vp, _int, _i64, _i64, _i64, _int, _c.c_longlong, _int, _vp, _vp, _sz, _vp]),
+    "sx_macenko_pfit_gather": (_int, [_vp, _int, _c.c_longlong, _int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sx_macenko_pfit_finish": (_int, [_vp, _vp, _int, _int, _int, _c.c_longlong, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sx_reinhard_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "sx_reinhard_sums": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sx_reinhard_apply": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _c.c_double, _vp, _vp, _vp, _sz, _vp]),
@@ -83,6 +91,15 @@ def library_available() -> bool:
 def hip_available() -> bool:
     """Library loaded AND a ROCm device is visible to torch."""
     return library_available() and torch.version.hip is not None and torch.cuda.is_available()
+
+
+def check_arch(device: torch.device) -> None:
+    """The code objects in the library are gfx950 (MI355X) only: say so instead of failing at the first launch."""
+    if not torch.cuda.is_available():
+        return
+    arch = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "") or ""
+    if arch and not arch.split(":")[0].startswith("gfx950"):
+        raise RuntimeError(f"libstainx_hip.so is built for gfx950 (MI355X); device {device} reports {arch}")
 
 
 def require():

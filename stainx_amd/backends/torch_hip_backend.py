@@ -40,6 +40,7 @@ class TorchHIPBackendBase:
         if self.device.index is None and torch.cuda.is_available():
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._lib = _native.require()
+        _native.check_arch(self.device)
         self._scratch = _native.Scratch()
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
@@ -165,6 +166,80 @@ class MacenkoHIP(TorchHIPBackendBase):
             rc = self._lib.sx_macenko_dfit_result(state.data_ptr(), he.data_ptr(), max_c.data_ptr(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_dfit_result")
         return he, max_c
+
+    # ---- the same pooled fit across ranks on the bracket machinery (three passes; see stainx_amd/distributed.py) ----
+    def _pfit_ws(self, n: int, h: int, w: int) -> torch.Tensor:
+        return self._scratch.get(self._lib.sx_macenko_workspace_bytes(n, h, w), self.device)
+
+    def pfit_sample_count(self, n: int, h: int, w: int) -> int:
+        return int(self._lib.sx_macenko_pfit_sample_count(n, h, w))
+
+    def pfit_stats(self, images: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """Local raw moments (10 float64) and the local sample's optical density (3, 4096) float32."""
+        images = images.to(self.device)
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"Macenko fit expects NCHW with C=3, got shape {tuple(images.shape)}")
+        images = images.contiguous()
+        n, _, h, w = images.shape
+        mom = torch.empty(10, dtype=torch.float64, device=self.device)
+        sample = torch.empty((3, 4096), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_stats(images.data_ptr(), _dtype_code(images), n, h, w, mom.data_ptr(), sample.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_stats")
+        self.last_workspace = ws
+        return mom, sample
+
+    def pfit_plane(self, moments: torch.Tensor, n_all: int, sample_union: torch.Tensor, sample_count: int, shape: tuple[int, int, int]) -> None:
+        n, h, w = shape
+        moments = moments.to(self.device, torch.float64).contiguous()
+        sample_union = sample_union.to(self.device, torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_plane(moments.data_ptr(), int(n_all), sample_union.data_ptr(), int(sample_count), n, h, w, ws.data_ptr(), ws.numel(),
+                                                 _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_plane")
+
+    def pfit_pass(self, images: torch.Tensor, stage: int, n_all: int, sample_count: int) -> torch.Tensor:
+        images = images.to(self.device).contiguous()
+        n, _, h, w = images.shape
+        sums = torch.empty(_native.PFIT_SUMS, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_pass(images.data_ptr(), _dtype_code(images), n, h, w, int(stage), int(n_all), int(sample_count), sums.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_pass")
+        return sums
+
+    def pfit_gather(self, sums_global: torch.Tensor, stage: int, n_all: int, sample_count: int, shape: tuple[int, int, int], share: int) -> tuple[torch.Tensor, torch.Tensor]:
+        n, h, w = shape
+        sums_global = sums_global.to(self.device, torch.int64).contiguous()
+        compact = torch.zeros((2, int(share)), dtype=torch.int32, device=self.device)
+        counts = torch.empty(2, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_gather(sums_global.data_ptr(), int(stage), int(n_all), int(sample_count), n, h, w, int(share), compact.data_ptr(), counts.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_gather")
+        return compact, counts
+
+    def pfit_finish(self, gathered_compact: torch.Tensor, gathered_counts: torch.Tensor, stage: int, n_all: int, sample_count: int, shape: tuple[int, int, int]):
+        """Stage 0: nothing returned.  Stage 1: (HE, maxC, status) -- status is a device int32, non-zero if a bracket missed."""
+        n, h, w = shape
+        world, share = int(gathered_counts.shape[0]), int(gathered_compact.shape[-1])
+        gathered_compact = gathered_compact.to(self.device, torch.int32).contiguous()
+        gathered_counts = gathered_counts.to(self.device, torch.int32).contiguous()
+        he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
+        max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_finish(gathered_compact.data_ptr(), gathered_counts.data_ptr(), world, share, int(stage), int(n_all), int(sample_count), n, h, w,
+                                                  he.data_ptr(), max_c.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_finish")
+        self.last_workspace = ws
+        return (he, max_c, status) if stage == 1 else None
 
     def tile_params(self, n_groups: int) -> dict[str, torch.Tensor]:
         """Intermediates of the last transform (per tile) or fit (one pooled group); used by tests."""

@@ -87,6 +87,8 @@ struct Geometry {
     uint32_t cap;                 // candidate keys per selection slot
     int interleaved;              // 1: tiles are (H,W,3) -- the three values of a pixel side by side -- instead of three planes
     int spread;                   // 1: pooled group of several tiles; candidates, counters and histograms stay per tile (PoolState)
+    int distributed;              // 1: the group also spans other ranks (sx_macenko_pfit_*): totals come from the host, no local fallback
+    long long n_all;              // distributed: pixels of the whole group over all ranks
 };
 
 // Pooled fit over several tiles ("spread" mode): the streaming stages keep candidates, counters and histograms per
@@ -100,6 +102,7 @@ struct alignas(256) PoolState {
     uint32_t compact_n[kSlots];
     uint32_t rank_in_bin[kSlots], range[kSlots][2];
     uint32_t ok[kSlots], overflow;     // overflow bit s: a tile's candidate buffer overflowed in slot s
+    uint32_t status;                   // distributed fit: non-zero when a bracket did not hold (the caller falls back to the radix rounds)
     uint32_t compact[kSlots][kCompact];
 };
 
@@ -1188,14 +1191,18 @@ __device__ void all_pixel_moments(const T* __restrict__ images, const Geometry& 
 }
 
 template <typename T>
-__device__ void plane_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int allow_fallback, TileScratch* sh) {
+__device__ void plane_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int allow_fallback, TileScratch* sh, const double* __restrict__ given_moments = nullptr) {
     GroupState& st = ws.state[group];
     SX_STAMP(st, 0);
     reset_scratch(sh);
     // the sample is fetched first: its latency hides behind the moments and the eigen-decomposition
     float sod[kKeys][3];
     load_sample(ws, group, g.sample_count, sod);
-    {
+    if (given_moments) {      // distributed fit: the moments of the whole group, already summed over the ranks
+        if (threadIdx.x < kPartial) sh->mom[threadIdx.x] = get(&given_moments[threadIdx.x]);
+        if (threadIdx.x == kPartial) sh->mom[kPartial] = (double)g.n_all;
+        if (threadIdx.x > kPartial && threadIdx.x < kMoments) sh->mom[threadIdx.x] = 0.0;
+    } else {
         // fixed-order (deterministic) sum of the work items' partial moments: lanes fetch them in parallel, one
         // thread per moment adds them in index order
         const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
@@ -1581,6 +1588,12 @@ __device__ void resolve_pair_spread(const T* __restrict__ images, const Geometry
             const uint32_t* keys = pool->compact[slot];
             if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
             key_out[j] = radix_select_stream((unsigned long long)n, (unsigned long long)want, [keys](unsigned long long i, uint32_t& k) { k = get(&keys[i]); return true; }, sh);
+        } else if (g.distributed) {      // the other ranks' pixels are out of reach: report, the caller repeats with the radix rounds
+            if (threadIdx.x == 0) {
+                atomicOr(&st.fell_back, 1u << slot);
+                put(&ws.pool->status, 1u);
+            }
+            key_out[j] = 0u;
         } else {      // bracket missed or a buffer overflowed: recompute every key of the group (exact, slow)
             if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << slot);
             key_out[j] = select_whole_group<T>(images, g, 0, slot, get(&st.rank[slot]), coef, use_all, sh);
@@ -1635,7 +1648,7 @@ __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, con
     float pinv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) pinv[i] = sh->coef[i];
-    const unsigned long long n_all = (unsigned long long)gp.count;
+    const unsigned long long n_all = g.distributed ? (unsigned long long)g.n_all : (unsigned long long)gp.count;
     const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
     uint32_t key[2][kKeys];
 #pragma unroll
@@ -1774,16 +1787,29 @@ struct alignas(256) DFitState {
     int round[2];
 };
 
-__global__ void dfit_reduce_partials_kernel(const double* __restrict__ partial, int64_t nblk, double n_all, double* __restrict__ moments) {
-    const int k = threadIdx.x;
-    if (k >= kMoments) return;
-    double s = 0.0;
-    if (k < kPartial) {
-        for (int64_t b = 0; b < nblk; ++b) s += partial[b * kPartial + k];
-    } else if (k == kPartial) {
-        s = n_all;        // all-pixel set: only its count is used by the distributed fit (no fallback there)
+// Sum of the work items' partial moments by one 256-thread workgroup in a fixed order (a function of nblk only): thread
+// (part, k) adds rows part, part + 25, ... of moment k, thread k then adds the 25 partial sums in order.
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ partial, int64_t nblk) {
+    __shared__ double part_sum[25][kPartial];
+    const int k = threadIdx.x % kPartial, part = threadIdx.x / kPartial;
+    if (part < 25) {
+        double s = 0.0;
+        for (int64_t b = part; b < nblk; b += 25) s += partial[b * kPartial + k];
+        part_sum[part][k] = s;
     }
-    moments[k] = s;
+    __syncthreads();
+    double total = 0.0;
+    if (threadIdx.x < kPartial)
+        for (int p = 0; p < 25; ++p) total += part_sum[p][threadIdx.x];
+    return total;      // valid in threads 0..9
+}
+
+__global__ __launch_bounds__(256) void dfit_reduce_partials_kernel(const double* __restrict__ partial, int64_t nblk, double n_all, double* __restrict__ moments) {
+    const double s = reduce_partials(partial, nblk);
+    const int k = threadIdx.x;
+    if (k < kPartial) moments[k] = s;
+    else if (k == kPartial) moments[k] = n_all;        // all-pixel set: only its count is used by the distributed fit (no fallback there)
+    else if (k < kMoments) moments[k] = 0.0;
 }
 
 __global__ void dfit_begin_kernel(const double* __restrict__ moments, DFitState* __restrict__ st) {
@@ -1995,6 +2021,91 @@ static int fit_typed(const void* images, const Geometry& g0, const Workspace& ws
                : run_estimate<T, 1>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream);
 }
 
+// ---- distributed pooled fit on the bracket machinery (sx_macenko_pfit_*) ---------------------------------
+constexpr int kPoolSums = 1024 + 2 * kSlots + 1;      // hist[2][2][256], below[4], ncand[4], overflow
+static_assert(kPoolSums == SX_PFIT_SUMS, "header constant");
+
+// local partial moments -> 10 doubles; the local sample (group 0) -> caller buffer
+__global__ __launch_bounds__(256) void pfit_export_stats_kernel(Workspace ws, int64_t nblk, double* __restrict__ moments_out, float* __restrict__ sample_out) {
+    if (blockIdx.x == 0) {
+        const double s = reduce_partials(ws.partial, nblk);
+        if (threadIdx.x < kPartial) moments_out[threadIdx.x] = s;
+    } else {
+        for (int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x; i < 3 * kSample; i += (gridDim.x - 1) * blockDim.x) sample_out[i] = ws.sample_od[i];
+    }
+}
+
+__global__ void pfit_import_sample_kernel(Workspace ws, const float* __restrict__ sample_union) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * kSample; i += gridDim.x * blockDim.x) ws.sample_od[i] = sample_union[i];
+}
+
+__global__ __launch_bounds__(kGroupThreads) void pfit_plane_kernel(Geometry g, Workspace ws, const double* __restrict__ moments) {
+    __shared__ TileScratch sh;
+    plane_stage<float>(nullptr, g, ws, 0, 0, &sh, moments);      // no fallback in a fit: the pixels are never touched
+}
+
+__global__ void pfit_export_sums_kernel(Workspace ws, long long* __restrict__ sums_out) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(ws.pool);
+    for (int i = threadIdx.x; i < kPoolSums; i += blockDim.x) {
+        uint32_t v;
+        if (i < 1024) v = src[i];
+        else if (i < 1024 + kSlots) v = ws.pool->below[i - 1024];
+        else if (i < 1024 + 2 * kSlots) v = ws.pool->ncand[i - 1024 - kSlots];
+        else v = ws.pool->overflow;
+        sums_out[i] = (long long)v;
+    }
+}
+
+__global__ void pfit_import_sums_kernel(Workspace ws, const long long* __restrict__ sums, int stage) {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(ws.pool);
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) dst[stage * 512 + i] = (uint32_t)sums[stage * 512 + i];
+    if (threadIdx.x < 2) {
+        const int slot = 2 * stage + threadIdx.x;
+        ws.pool->below[slot] = (uint32_t)sums[1024 + slot];
+        ws.pool->ncand[slot] = (uint32_t)sums[1024 + kSlots + slot];
+    }
+    if (threadIdx.x == 0) {
+        ws.pool->overflow = sums[1024 + 2 * kSlots] ? 0xFu : 0u;
+        ws.pool->compact_n[2 * stage] = ws.pool->compact_n[2 * stage + 1] = 0u;
+    }
+}
+
+__global__ void pfit_export_compact_kernel(Workspace ws, int stage, int share, uint32_t* __restrict__ compact_out, int* __restrict__ counts_out) {
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t n = ws.pool->compact_n[2 * stage + j];
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < min(n, (uint32_t)share); i += gridDim.x * blockDim.x) compact_out[(size_t)j * share + i] = ws.pool->compact[2 * stage + j][i];
+        if (blockIdx.x == 0 && threadIdx.x == 0) counts_out[j] = (int)n;
+    }
+}
+
+// the ranks' compact lists, gathered: [world][2][share] keys and [world][2] counts -> the union in the pool
+__global__ void pfit_merge_kernel(Workspace ws, int stage, int world, int share, const uint32_t* __restrict__ gathered, const int* __restrict__ counts) {
+    __shared__ uint32_t base[64][2];
+    if (threadIdx.x < 2) {
+        uint32_t run = 0;
+        bool bad = false;
+        for (int r = 0; r < world; ++r) {
+            base[r][threadIdx.x] = run;
+            const int n = counts[r * 2 + threadIdx.x];
+            if (n > share) bad = true;
+            run += (uint32_t)min(n, share);
+        }
+        ws.pool->compact_n[2 * stage + threadIdx.x] = run;
+        if (bad || run > (uint32_t)kCompact) ws.pool->status = 1u;
+    }
+    __syncthreads();
+    for (int r = 0; r < world; ++r)
+        for (int j = 0; j < 2; ++j) {
+            const int n = min(counts[r * 2 + j], share);
+            for (int i = threadIdx.x; i < n; i += blockDim.x)
+                if (base[r][j] + i < (uint32_t)kCompact) ws.pool->compact[2 * stage + j][base[r][j] + i] = gathered[((size_t)r * 2 + j) * share + i];
+        }
+}
+
+__global__ void pfit_status_kernel(Workspace ws, int* __restrict__ status_out) {
+    if (threadIdx.x == 0) status_out[0] = (int)(ws.pool->status | (ws.state[0].fell_back & 0xFu));
+}
+
 // ---- distributed pooled fit: staged entry points (host does the all-reduces in between) -----------
 template <typename T>
 static int dfit_moments_typed(const void* images, const Geometry& g0, const Workspace& ws, double* moments, hipStream_t stream) {
@@ -2009,7 +2120,7 @@ static int dfit_moments_typed(const void* images, const Geometry& g0, const Work
         hipLaunchKernelGGL((stats_kernel<T, W>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
     else
         hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
-    hipLaunchKernelGGL(dfit_reduce_partials_kernel, dim3(1), dim3(64), 0, stream, ws.partial, (int64_t)grid, (double)(g.n_tiles * g.pixels), moments);
+    hipLaunchKernelGGL(dfit_reduce_partials_kernel, dim3(1), dim3(256), 0, stream, ws.partial, (int64_t)grid, (double)(g.n_tiles * g.pixels), moments);
     return check_launch("macenko dfit moments");
 }
 
@@ -2027,6 +2138,31 @@ static int dfit_histogram_typed(const void* images, const Geometry& g0, const DF
     else
         hipLaunchKernelGGL((dfit_histogram_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, stage, hist);
     return check_launch("macenko dfit histogram");
+}
+
+template <typename T>
+static int pfit_pass_typed(const void* images, const Geometry& g0, const Workspace& ws, int stage, long long* sums_out, hipStream_t stream) {
+    Geometry g = g0;
+    constexpr int W = PackOf<T>::n;
+    const bool vec = (g.pixels % W == 0) && aligned_for(images, 16);
+    g.vec = vec ? 1 : 0;
+    const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
+    const T* in = static_cast<const T*>(images);
+    if (stage < 0) {      // stats
+        if (vec) hipLaunchKernelGGL((stats_kernel<T, W>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
+        else hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
+        return check_launch("macenko pfit stats");
+    }
+    if (stage == 0) {
+        if (vec) hipLaunchKernelGGL((bracket_kernel<T, W, false>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
+        else hipLaunchKernelGGL((bracket_kernel<T, 1, false>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
+    } else {
+        if (vec) hipLaunchKernelGGL((bracket_kernel<T, W, true>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
+        else hipLaunchKernelGGL((bracket_kernel<T, 1, true>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
+    }
+    hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)g.n_tiles), dim3(512), 0, stream, g, ws, stage);
+    hipLaunchKernelGGL(pfit_export_sums_kernel, dim3(1), dim3(256), 0, stream, ws, sums_out);
+    return check_launch("macenko pfit pass");
 }
 
 }  // namespace macenko
@@ -2053,7 +2189,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -2071,7 +2207,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2098,7 +2234,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2120,7 +2256,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
@@ -2143,4 +2279,106 @@ extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* m
     if (!state || !he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "bad argument to sx_macenko_dfit_result");
     hipLaunchKernelGGL(dfit_result_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_ptr), static_cast<const DFitState*>(state), he_out, max_c_out);
     return check_launch("macenko dfit result");
+}
+
+// ------------------------------------------------------------------------------------------------
+// distributed pooled fit on the bracket machinery: see include/stainx_hip.h
+// ------------------------------------------------------------------------------------------------
+static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, int sample_count) {
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
+    set_sampling(g);                 // local sample stride; cap per tile
+    g.spread = 1;                    // also for a single local tile: the group spans other ranks
+    g.cap = cap_for(g.pixels);
+    g.distributed = 1;
+    g.n_all = n_all;
+    if (sample_count >= 0) g.sample_count = sample_count;
+    return g;
+}
+
+extern "C" int sx_macenko_pfit_sample_count(int64_t n, int64_t h, int64_t w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
+    set_sampling(g);
+    return g.sample_count;
+}
+
+extern "C" int sx_macenko_pfit_stats(const void* images, int dtype, int64_t n, int64_t h, int64_t w, double* moments_out, float* sample_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
+    if (rc != SX_OK) return rc;
+    if (!moments_out || !sample_out) return fail(SX_ERR_BAD_ARG, "moments_out / sample_out pointer is null");
+    const Geometry g = pfit_geometry(n, h, w, 0, -1);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    switch (dtype) {
+        case SX_U8: rc = pfit_pass_typed<uint8_t>(images, g, ws, -1, nullptr, stream); break;
+        case SX_F16: rc = pfit_pass_typed<__half>(images, g, ws, -1, nullptr, stream); break;
+        case SX_BF16: rc = pfit_pass_typed<__hip_bfloat16>(images, g, ws, -1, nullptr, stream); break;
+        case SX_F32: rc = pfit_pass_typed<float>(images, g, ws, -1, nullptr, stream); break;
+        case SX_F64: rc = pfit_pass_typed<double>(images, g, ws, -1, nullptr, stream); break;
+        default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    }
+    if (rc != SX_OK) return rc;
+    hipLaunchKernelGGL(pfit_export_stats_kernel, dim3(13), dim3(256), 0, stream, ws, (int64_t)(g.n_tiles * g.blocks_per_tile), moments_out, sample_out);
+    return check_launch("macenko pfit stats export");
+}
+
+extern "C" int sx_macenko_pfit_plane(const double* moments, long long n_all, const float* sample_union, int sample_count, int64_t n, int64_t h, int64_t w, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    if (!moments || !sample_union || !ws_ptr) return fail(SX_ERR_BAD_ARG, "moments / sample_union / workspace pointer is null");
+    if (n <= 0 || h <= 0 || w <= 0 || n_all <= 0 || sample_count < 0 || sample_count > kSample) return fail(SX_ERR_BAD_ARG, "bad sizes");
+    if (ws_bytes < sx_macenko_workspace_bytes(n, h, w)) return fail(SX_ERR_WORKSPACE, "workspace too small");
+    const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    hipLaunchKernelGGL(pfit_import_sample_kernel, dim3(12), dim3(256), 0, stream, ws, sample_union);
+    hipLaunchKernelGGL(pfit_plane_kernel, dim3(1), dim3(kGroupThreads), 0, stream, g, ws, moments);
+    return check_launch("macenko pfit plane");
+}
+
+extern "C" int sx_macenko_pfit_pass(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int stage, long long n_all, int sample_count, long long* sums_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
+    if (rc != SX_OK) return rc;
+    if (!sums_out || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "sums_out is null or stage is not 0/1");
+    const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    switch (dtype) {
+        case SX_U8: return pfit_pass_typed<uint8_t>(images, g, ws, stage, sums_out, stream);
+        case SX_F16: return pfit_pass_typed<__half>(images, g, ws, stage, sums_out, stream);
+        case SX_BF16: return pfit_pass_typed<__hip_bfloat16>(images, g, ws, stage, sums_out, stream);
+        case SX_F32: return pfit_pass_typed<float>(images, g, ws, stage, sums_out, stream);
+        case SX_F64: return pfit_pass_typed<double>(images, g, ws, stage, sums_out, stream);
+        default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    }
+}
+
+extern "C" int sx_macenko_pfit_gather(const long long* sums_global, int stage, long long n_all, int sample_count, int64_t n, int64_t h, int64_t w, int share, unsigned* compact_out, int* counts_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    if (share < 1 || share > kCompact) return fail(SX_ERR_BAD_ARG, "share must be in [1, %d]", kCompact);
+    if (!sums_global || !compact_out || !counts_out || !ws_ptr || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "null pointer or bad stage");
+    if (n <= 0 || h <= 0 || w <= 0 || ws_bytes < sx_macenko_workspace_bytes(n, h, w)) return fail(SX_ERR_WORKSPACE, "bad sizes or workspace too small");
+    const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    hipLaunchKernelGGL(pfit_import_sums_kernel, dim3(1), dim3(256), 0, stream, ws, sums_global, stage);
+    hipLaunchKernelGGL(pool_gather_kernel, dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, g, ws, stage);
+    hipLaunchKernelGGL(pfit_export_compact_kernel, dim3(8), dim3(256), 0, stream, ws, stage, share, compact_out, counts_out);
+    return check_launch("macenko pfit gather");
+}
+
+extern "C" int sx_macenko_pfit_finish(const unsigned* gathered_compact, const int* gathered_counts, int world, int share, int stage, long long n_all, int sample_count, int64_t n, int64_t h, int64_t w,
+                                      float* he_out, float* max_c_out, int* status_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    if (!gathered_compact || !gathered_counts || !ws_ptr || (stage != 0 && stage != 1) || world < 1 || world > 64) return fail(SX_ERR_BAD_ARG, "null pointer, bad stage or world size");
+    if (stage == 1 && (!he_out || !max_c_out || !status_out)) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out / status_out pointer is null");
+    if (n <= 0 || h <= 0 || w <= 0 || ws_bytes < sx_macenko_workspace_bytes(n, h, w)) return fail(SX_ERR_WORKSPACE, "bad sizes or workspace too small");
+    if (share < 1 || (long long)world * share > kCompact) return fail(SX_ERR_BAD_ARG, "world x share = %d x %d exceeds the compact list (%d)", world, share, kCompact);
+    const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    hipLaunchKernelGGL(pfit_merge_kernel, dim3(1), dim3(1024), 0, stream, ws, stage, world, share, gathered_compact, gathered_counts);
+    if (stage == 0) {
+        hipLaunchKernelGGL((stain_kernel<float, true>), dim3(1), dim3(kGroupThreads), 0, stream, (const float*)nullptr, g, ws);
+    } else {
+        hipLaunchKernelGGL((scale_kernel<float, true>), dim3(1), dim3(kGroupThreads), 0, stream, (const float*)nullptr, g, ws, (const float*)nullptr, he_out, max_c_out);
+        hipLaunchKernelGGL(pfit_status_kernel, dim3(1), dim3(64), 0, stream, ws, status_out);
+    }
+    return check_launch("macenko pfit finish");
 }

@@ -31,18 +31,21 @@ def test_world_size_one_matches_fused_paths(golden):
     g = golden("g3_macenko_fit.npz")
     for tag in ("pooled4x224", "pooled8x128", "single64"):
         tiles = torch.from_numpy(g[f"{tag}_u8"]).to(dev)
-        he, max_c = sxd.macenko_fit_pooled(tiles)
-        np.testing.assert_allclose(he.cpu().numpy(), g[f"{tag}_he"], rtol=0, atol=5e-5)
-        np.testing.assert_allclose(max_c.cpu().numpy(), g[f"{tag}_max_c"], rtol=1e-4, atol=0)
         he2, mc2 = MacenkoHIP(dev).compute_reference_stain_matrix(tiles)
-        assert torch.equal(he, he2) and torch.equal(max_c, mc2)          # radix-select fit == bracketed fit, bit for bit
+        for method in ("brackets", "radix"):
+            he, max_c = sxd.macenko_fit_pooled(tiles, method=method)
+            np.testing.assert_allclose(he.cpu().numpy(), g[f"{tag}_he"], rtol=0, atol=5e-5)
+            np.testing.assert_allclose(max_c.cpu().numpy(), g[f"{tag}_max_c"], rtol=1e-4, atol=0)
+            assert torch.equal(he, he2) and torch.equal(max_c, mc2), method          # both staged forms == the fused fit, bit for bit
     # a pooled group far larger than one tile (2.1 M pixels): the candidate buffers scale with the group, no slow path
     many = synth.he_batch(32, 256, 256, seed0=400, scale_step=0.004).to(dev)
     be = MacenkoHIP(dev)
     he_b, mc_b = be.compute_reference_stain_matrix(many)
     assert int(be.tile_params(1)["fell_back"][0]) & 0xF == 0        # no whole-group select
-    he_d, mc_d = sxd.macenko_fit_pooled(many)
-    assert torch.equal(he_b, he_d) and torch.equal(mc_b, mc_d)
+    for method in ("brackets", "radix"):
+        he_d, mc_d = sxd.macenko_fit_pooled(many, method=method)
+        assert torch.equal(he_b, he_d) and torch.equal(mc_b, mc_d), method
+    assert sxd._macenko_fit_pooled_brackets(many, None, be) is not None, "the bracket form is expected to hold on ordinary tiles (no fallback to the radix rounds)"
     he_o, mc_o = so.macenko_fit(many.cpu().numpy(), signs="positive_sum")
     np.testing.assert_allclose(he_b.cpu().numpy(), he_o, rtol=0, atol=5e-5)
     np.testing.assert_allclose(mc_b.cpu().numpy(), mc_o, rtol=1e-4, atol=0)
@@ -63,7 +66,12 @@ def _worker(rank: int, world_size: int, port: int, out_dir: str):
         dev = torch.device("cuda:0")
         tiles = synth.he_batch(8, 128, 128)
         lo, hi = sxd.shard_bounds(8, rank, world_size)
-        he, max_c = sxd.macenko_fit_pooled(tiles[lo:hi].to(dev))
+        he, max_c = sxd.macenko_fit_pooled(tiles[lo:hi].to(dev))                     # bracket machinery, three passes
+        he_r, max_c_r = sxd.macenko_fit_pooled(tiles[lo:hi].to(dev), method="radix")   # radix rounds, nine passes
+        # a sharding with unequal parts and a one-tile rank
+        big = synth.he_batch(5, 96, 160, seed0=77)
+        part = big[:4] if rank == 0 else big[4:]
+        he_u, max_c_u = sxd.macenko_fit_pooled(part.to(dev))
         noise = synth.noise_u8((5, 3, 64, 64), 11)
         ref = synth.noise_u8((1, 3, 64, 64), 12)
         l2, h2 = sxd.shard_bounds(5, rank, world_size)
@@ -74,7 +82,8 @@ def _worker(rank: int, world_size: int, port: int, out_dir: str):
         hn = HistogramMatching(device=dev).fit(ref)
         hm = sxd.hm_transform_pooled(noise[l2:h2].to(dev), hn._ref_histograms_256)
         torch.cuda.synchronize()
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), he=he.cpu().numpy(), max_c=max_c.cpu().numpy(), rein=rein.cpu().numpy(), hm=hm.cpu().numpy())
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), he=he.cpu().numpy(), max_c=max_c.cpu().numpy(), he_r=he_r.cpu().numpy(), max_c_r=max_c_r.cpu().numpy(),
+                 he_u=he_u.cpu().numpy(), max_c_u=max_c_u.cpu().numpy(), rein=rein.cpu().numpy(), hm=hm.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -89,6 +98,14 @@ def test_two_ranks_on_one_gpu(tmp_path, golden):
         np.testing.assert_allclose(r["max_c"], g["pooled8x128_max_c"], rtol=1e-4, atol=0)
     np.testing.assert_array_equal(r0["he"], r1["he"])
     np.testing.assert_array_equal(r0["max_c"], r1["max_c"])
+    for r in (r0, r1):      # the two staged forms agree bit for bit, on every rank
+        np.testing.assert_array_equal(r["he"], r["he_r"])
+        np.testing.assert_array_equal(r["max_c"], r["max_c_r"])
+    he_o, mc_o = so.macenko_fit(synth.he_batch(5, 96, 160, seed0=77).numpy(), signs="positive_sum")
+    for r in (r0, r1):
+        np.testing.assert_allclose(r["he_u"], he_o, rtol=0, atol=5e-5)
+        np.testing.assert_allclose(r["max_c_u"], mc_o, rtol=1e-4, atol=0)
+    np.testing.assert_array_equal(r0["he_u"], r1["he_u"])
     noise = synth.noise_u8((5, 3, 64, 64), 11).numpy()
     ref = synth.noise_u8((1, 3, 64, 64), 12).numpy()
     want_hm = so.hm_transform(noise, so.hm_fit(ref))
