@@ -97,6 +97,109 @@ class NumpyMacenkoSteps:
         return torch.from_numpy(state["he"].copy()), torch.from_numpy(state["max_c"].copy())
 
 
+def _sample_geometry(n: int, h: int, w: int) -> tuple[int, int]:
+    """(stride, count) of the local pixel sample: the smallest power-of-two stride with at most 4096 samples."""
+    total, stride = n * h * w, 1
+    while (total + stride - 1) // stride > 4096:
+        stride *= 2
+    return stride, min(4096, (total + stride - 1) // stride)
+
+
+def _bracket_ranks(m: int, n_total: int, k0: int) -> tuple[int, int]:
+    f = k0 / (n_total - 1) if n_total > 1 else 0.0
+    r, sd = f * (m - 1), np.sqrt(m * f * (1 - f))
+    return int(min(max(np.floor(r - 6 * sd - 3), 0), m - 1)), int(min(max(np.ceil(r + 6 * sd + 3), 0), m - 1))
+
+
+class NumpyMacenkoBracketSteps(NumpyMacenkoSteps):
+    """The bracket form of the staged pooled fit (``pfit_*``): sample brackets, counts + 256-bin histogram of the keys
+    inside them, the candidates of the picked bin, exact selection on their union."""
+    device = torch.device("cpu")
+
+    def pfit_sample_count(self, n, h, w):
+        return _sample_geometry(n, h, w)[1]
+
+    def pfit_stats(self, images):
+        rows = self._od_rows(images)
+        mom = self.dfit_moments(images)[:10]
+        n, _, h, w = images.shape
+        stride, count = _sample_geometry(n, h, w)
+        sample = np.zeros((3, 4096), dtype=np.float32)
+        sample[:, :count] = rows[::stride][:count].T
+        return mom, torch.from_numpy(sample)
+
+    def pfit_plane(self, moments, n_all, sample_union, sample_count, shape):
+        full = torch.cat([moments.to(torch.float64), torch.tensor([float(n_all)] + [0.0] * 9, dtype=torch.float64)])
+        st = self.dfit_begin(full)
+        st["sample"] = sample_union.numpy()[:, :sample_count].T.astype(np.float32)          # (m,3)
+        kept = st["sample"][st["sample"].min(axis=1) >= so.BETA]
+        proj = (kept @ st["vecs"]).astype(np.float32)
+        keys = np.sort(float_key(np.arctan2(proj[:, 1], proj[:, 0]).astype(np.float32)))
+        st["brackets"] = [tuple(int(keys[i]) for i in _bracket_ranks(len(keys), st["n_sel"], st["rank"][s])) for s in (0, 1)]
+        self.state = st
+
+    def _bin(self, keys, lo, hi):
+        vlo, vhi = float(key_float(lo)), float(key_float(hi))
+        scale = 256.0 / (vhi - vlo) if vhi > vlo else 0.0
+        vals = np.array([key_float(k) for k in keys], dtype=np.float64) if len(keys) < 64 else keys_to_float(keys).astype(np.float64)
+        return np.clip(((vals - vlo) * scale), 0, 255).astype(np.int64)
+
+    def pfit_pass(self, images, stage, n_all, sample_count):
+        st = self.state
+        sums = np.zeros(1033, dtype=np.int64)
+        st["cand"] = []
+        for j, k in enumerate(self._keys(images, st, stage)):
+            lo, hi = st["brackets"][j]
+            inside = k[(k >= np.uint32(lo)) & (k <= np.uint32(hi))]
+            st["cand"].append(inside)
+            sums[stage * 512 + j * 256: stage * 512 + (j + 1) * 256] = np.bincount(self._bin(inside, lo, hi), minlength=256)
+            sums[1024 + 2 * stage + j] = int((k < np.uint32(lo)).sum())
+            sums[1028 + 2 * stage + j] = len(inside)
+        return torch.from_numpy(sums)
+
+    def pfit_gather(self, sums_global, stage, n_all, sample_count, shape, share):
+        st, g = self.state, sums_global.numpy()
+        compact = np.zeros((2, share), dtype=np.uint32)
+        counts = np.zeros(2, dtype=np.int32)
+        st["want"] = [0, 0]
+        for j in range(2):
+            want = st["rank"][2 * stage + j] - int(g[1024 + 2 * stage + j])
+            assert 0 <= want < int(g[1028 + 2 * stage + j]), "bracket missed in the stand-in"
+            cum = np.cumsum(g[stage * 512 + j * 256: stage * 512 + (j + 1) * 256])
+            b = int(np.searchsorted(cum, want, side="right"))
+            st["want"][j] = want - (int(cum[b - 1]) if b else 0)
+            lo, hi = st["brackets"][j]
+            mine = st["cand"][j][self._bin(st["cand"][j], lo, hi) == b]
+            counts[j] = len(mine)
+            compact[j, : len(mine)] = mine
+        return torch.from_numpy(compact.view(np.int32)), torch.from_numpy(counts)
+
+    def pfit_finish(self, gathered_compact, gathered_counts, stage, n_all, sample_count, shape):
+        st = self.state
+        keys = []
+        for j in range(2):
+            parts = [gathered_compact[r, j, : int(gathered_counts[r, j])].numpy().view(np.uint32) for r in range(gathered_counts.shape[0])]
+            keys.append(int(np.sort(np.concatenate(parts))[st["want"][j]]))
+        if stage == 0:
+            st["he"] = so.stain_vectors_from_angles(st["vecs"], key_float(keys[0]), key_float(keys[1]))
+            st["pinv"] = np.linalg.pinv(st["he"].astype(np.float64)).astype(np.float32)
+            st["rank"][2] = st["rank"][3] = nearest_rank_index(99, n_all)
+            conc = (st["pinv"] @ st["sample"].T).astype(np.float32)
+            st["brackets"] = []
+            for j in range(2):
+                ks = np.sort(float_key(conc[j]))
+                st["brackets"].append(tuple(int(ks[i]) for i in _bracket_ranks(len(ks), n_all, st["rank"][2 + j])))
+            return None
+        max_c = np.array([key_float(keys[0]), key_float(keys[1])], dtype=np.float32)
+        return torch.from_numpy(st["he"].copy()), torch.from_numpy(max_c), torch.zeros(1, dtype=torch.int32)
+
+
+def keys_to_float(keys: np.ndarray) -> np.ndarray:
+    k = np.ascontiguousarray(keys, dtype=np.uint32)
+    u = np.where(k >> 31 != 0, k & np.uint32(0x7FFFFFFF), ~k)
+    return u.astype(np.uint32).view(np.float32)
+
+
 class NumpyReinhardSteps:
     def local_sums(self, images):
         lab = so.rgb_to_lab(so.to_unit_float(images.numpy())).astype(np.float64) - 128.0

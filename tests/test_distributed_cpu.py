@@ -23,7 +23,7 @@ def _free_port() -> int:
 
 
 def _worker(rank: int, world_size: int, port: int, out_dir: str):
-    from tests._numpy_steps import NumpyHMSteps, NumpyMacenkoSteps, NumpyReinhardSteps
+    from tests._numpy_steps import NumpyHMSteps, NumpyMacenkoBracketSteps, NumpyMacenkoSteps, NumpyReinhardSteps
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
@@ -31,13 +31,16 @@ def _worker(rank: int, world_size: int, port: int, out_dir: str):
         tiles = synth.he_batch(5, 64, 64, seed0=200, scale_step=0.04)          # 5 tiles over 2 ranks: 3 + 2
         lo, hi = sxd.shard_bounds(tiles.shape[0], rank, world_size)
         local = tiles[lo:hi]
-        he, max_c = sxd.macenko_fit_pooled(local, steps=NumpyMacenkoSteps())
+        he, max_c = sxd.macenko_fit_pooled(local, steps=NumpyMacenkoSteps())                 # no pfit_* steps: the radix form
+        bracket_steps = NumpyMacenkoBracketSteps()
+        he_b, max_c_b = sxd.macenko_fit_pooled(local, steps=bracket_steps)                  # the bracket form (default)
+        assert hasattr(bracket_steps, "state"), "the bracket choreography did not run"
         noise = synth.noise_u8((5, 3, 32, 32), 11)
         ref_mean, ref_std = so.reinhard_fit(synth.noise_u8((1, 3, 32, 32), 12).numpy())
         rein = sxd.reinhard_transform_pooled(noise[lo:hi], ref_mean, ref_std, steps=NumpyReinhardSteps())
         hists = so.hm_fit(synth.noise_u8((1, 3, 32, 32), 12).numpy())
         hm = sxd.hm_transform_pooled(noise[lo:hi], hists, steps=NumpyHMSteps())
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), he=he.numpy(), max_c=max_c.numpy(), rein=rein.numpy(), hm=hm.numpy(), lo=lo, hi=hi)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), he=he.numpy(), max_c=max_c.numpy(), he_b=he_b.numpy(), max_c_b=max_c_b.numpy(), rein=rein.numpy(), hm=hm.numpy(), lo=lo, hi=hi)
     finally:
         dist.destroy_process_group()
 
@@ -60,6 +63,9 @@ def test_two_rank_gloo_matches_single_process_oracle(tmp_path):
         np.testing.assert_allclose(r["he"], he, atol=2e-5)
         np.testing.assert_allclose(r["max_c"], max_c, rtol=2e-5)
     np.testing.assert_array_equal(r0["he"], r1["he"])                    # rank-invariant bits
+    for r in (r0, r1):                                                   # bracket form: same answer, same bits on both ranks
+        np.testing.assert_array_equal(r["he_b"], r["he"])
+        np.testing.assert_array_equal(r["max_c_b"], r["max_c"])
     np.testing.assert_array_equal(r0["max_c"], r1["max_c"])
     assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 3, 3, 5)
     noise = synth.noise_u8((5, 3, 32, 32), 11).numpy()
