@@ -266,6 +266,25 @@ def _cumsum_f32(values: np.ndarray) -> np.ndarray:
     return np.cumsum(values.astype(np.float64)).astype(F32)
 
 
+def _torch_sum_f32(values: np.ndarray) -> np.float32:
+    """``torch.sum`` of a contiguous float32 vector on CPU whose length is a multiple of 32 (the 256-bin histograms here):
+    ATen's vectorised reduction -- four accumulators of eight lanes over blocks of 32, the accumulators added in order,
+    then the lanes in order.  Not a running sum: the last bit differs from one for ~20 % of histograms (checked against
+    torch 2.10 by tools/check_torch_sum.py)."""
+    x = np.ascontiguousarray(values, dtype=F32)
+    assert x.size % 32 == 0
+    acc = np.zeros((4, 8), dtype=F32)
+    for block in x.reshape(-1, 4, 8):
+        acc = (acc + block).astype(F32)
+    lanes = acc[0]
+    for k in range(1, 4):
+        lanes = (lanes + acc[k]).astype(F32)
+    total = lanes[0]
+    for lane in lanes[1:]:
+        total = F32(total + lane)
+    return F32(total)
+
+
 def hm_fit(images: np.ndarray, channel_axis: int = 1) -> list[np.ndarray]:
     """Per-channel normalised 256-bin histograms (torch_backend.py:139-179); what ``transform`` receives."""
     chw, _ = _channels_first(images, channel_axis)
@@ -273,7 +292,7 @@ def hm_fit(images: np.ndarray, channel_axis: int = 1) -> list[np.ndarray]:
     hists = []
     for c in range(u8.shape[1]):
         counts = np.bincount(u8[:, c].reshape(-1), minlength=256).astype(F32)
-        hists.append(counts / (counts.sum(dtype=F32) + F32(1e-8)))          # :140-141
+        hists.append(counts / (_torch_sum_f32(counts) + F32(1e-8)))          # :140-141
     return hists
 
 
@@ -282,7 +301,7 @@ def hm_lut(counts: np.ndarray, ref_hist: np.ndarray, num_pixels: int) -> np.ndar
     src_hist = counts.astype(F32) / F32(num_pixels + 1e-8)                   # :235
     src_cdf = _cumsum_f32(src_hist)                                          # :236
     ref = ref_hist.astype(F32)
-    ref_cdf = _cumsum_f32(ref / (ref.sum(dtype=F32) + F32(1e-8)))            # :222-223
+    ref_cdf = _cumsum_f32(ref / (_torch_sum_f32(ref) + F32(1e-8)))            # :222-223
     values = np.arange(256, dtype=F32)
     idx = np.searchsorted(ref_cdf, src_cdf, side="left")                     # :260
     idx = np.clip(idx, 1, 255)                                               # :261

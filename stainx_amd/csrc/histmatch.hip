@@ -121,14 +121,38 @@ __global__ __launch_bounds__(kThreads) void histogram_planar_kernel(const T* __r
     }
 }
 
+// torch.sum() of 256 contiguous float32 on the CPU (the reference's `counts.sum()` / `ref_hist.float().sum()`,
+// torch_backend.py:141,222): not a plain running sum -- ATen's vectorised reduction keeps four accumulators of eight lanes
+// over blocks of 32 elements, adds the accumulators in order, then the eight lanes in order.  Reproduced as is (verified
+// against torch 2.10 on 300 random histograms, tools/check_torch_sum.py): a sum accumulated any other way differs in the
+// last bit for ~20 % of histograms, which moves LUT entries by 1e-7 and flips a grey level at truncation boundaries.
+template <class At>
+__device__ inline float torch_sum_256(At at) {
+    float acc[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[k][l] = 0.0f;
+    for (int i = 0; i < kBins / 32; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[k][l] = __fadd_rn(acc[k][l], at(i * 32 + k * 8 + l));
+    float total = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const float lane = __fadd_rn(__fadd_rn(__fadd_rn(acc[0][l], acc[1][l]), acc[2][l]), acc[3][l]);
+        total = l == 0 ? lane : __fadd_rn(total, lane);
+    }
+    return total;
+}
+
 // fit: normalised histogram  counts / (sum(counts) + 1e-8)  in float32 (torch_backend.py:139-141)
 __global__ void normalise_kernel(const uint32_t* __restrict__ counts, float* __restrict__ hist_out) {
     const int c = blockIdx.x;
     __shared__ float total_s;
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int b = 0; b < kBins; ++b) t += (double)(float)counts[c * kBins + b];
-        total_s = (float)t + 1e-8f;
+        total_s = torch_sum_256([&](int b) { return (float)counts[c * kBins + b]; }) + 1e-8f;
     }
     __syncthreads();
     hist_out[c * kBins + threadIdx.x] = (float)counts[c * kBins + threadIdx.x] / total_s;
@@ -155,9 +179,7 @@ __global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, co
     // the divisions run one per thread; only the two running sums are sequential (that order is torch.cumsum's)
     if (t == 64) {
         // reference: h / (sum(h) + 1e-8) (:222-223)
-        double tot = 0.0;
-        for (int b = 0; b < kBins; ++b) tot += (double)ref_hist[c * kBins + b];
-        ref_denom_s = (float)tot + 1e-8f;
+        ref_denom_s = torch_sum_256([&](int b) { return ref_hist[c * kBins + b]; }) + 1e-8f;
     }
     // source: counts / float(num_pixels + 1e-8) (:235)
     // (the local histogram is read as it was counted; counts pooled over ranks arrive widened to 64 bits)

@@ -195,3 +195,17 @@ def test_color_round_trip():
     assert np.abs(back - rgb).max() < 3e-2
     lab = so.rgb_to_lab(np.full((1, 3, 4, 4), 1.2, dtype=np.float32))
     assert lab[:, 0].min() > 50.0
+
+
+def test_histogram_matching_random_cases_bit_exact(golden):
+    """g9: 80 random small cases.  The LUT hinges on the last bit of `ref_hist.sum()`, which torch adds up in its
+    vectorised order (oracle._torch_sum_f32); every output must equal the reference's, bit for bit."""
+    from tests.golden.cases import g9_cases
+
+    g = golden("g9_hm_random.npz")
+    for i, (n, h, w, name, s_src, s_ref) in enumerate(g9_cases()):
+        x = synth.as_dtype(synth.noise_u8((n, 3, h, w), s_src), TORCH_DTYPES[name]).numpy()
+        ref = synth.as_dtype(synth.noise_u8((1, 3, h, w), s_ref), TORCH_DTYPES[name]).numpy()
+        got = so.hm_transform(x, so.hm_fit(ref))
+        want = g[f"c{i}_out"]
+        assert got.dtype == want.dtype and np.array_equal(got, want), (i, n, h, w, name)

@@ -135,3 +135,20 @@ def test_histogram_matching_errors(dev):
         be.transform(x, torch.rand(128))
     with pytest.raises(TypeError, match="must be a torch.Tensor"):
         be.transform(x, [np.zeros(256)])
+
+
+def test_histogram_matching_random_cases_bit_exact(golden):
+    """g9: 80 random small cases from the real reference (odd sizes, four dtypes).  The output hinges on the last bit of
+    the float32 sums of the 256-bin histograms; the kernels add them in ATen's order (torch_sum_256)."""
+    from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
+    from tests.golden.cases import g9_cases
+
+    dev = torch.device("cuda:0")
+    g = golden("g9_hm_random.npz")
+    hb = HistogramMatchingHIP(dev, channel_axis=1)
+    for i, (n, h, w, name, s_src, s_ref) in enumerate(g9_cases()):
+        x = synth.as_dtype(synth.noise_u8((n, 3, h, w), s_src), TORCH_DTYPES[name])
+        ref = synth.as_dtype(synth.noise_u8((1, 3, h, w), s_ref), TORCH_DTYPES[name])
+        got = hb.transform(x.to(dev), hb.compute_reference_histograms(ref.to(dev))).cpu().numpy()
+        want = g[f"c{i}_out"]
+        assert got.dtype == want.dtype and np.array_equal(got, want), (i, n, h, w, name)
