@@ -89,6 +89,7 @@ struct Geometry {
     int spread;                   // 1: pooled group of several tiles; candidates, counters and histograms stay per tile (PoolState)
     int distributed;              // 1: the group also spans other ranks (sx_macenko_pfit_*): totals come from the host, no local fallback
     long long n_all;              // distributed: pixels of the whole group over all ranks
+    int fine_chunk, fine_blocks;  // small batches: pixels per work item / work items per tile of the bracket and reconstruct stages (0: kChunk)
 };
 
 // Pooled fit over several tiles ("spread" mode): the streaming stages keep candidates, counters and histograms per
@@ -951,8 +952,9 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
     const int group = g.pooled ? 0 : (int)tile;
     GroupState& st = ws.state[group];
     constexpr int s0 = kConc ? 2 : 0;
-    const int64_t p_begin = (int64_t)chunk_id * kChunk;
-    const int64_t p_end = min(p_begin + (int64_t)kChunk, g.pixels);
+    const int64_t chunk = g.fine_chunk ? g.fine_chunk : kChunk;
+    const int64_t p_begin = (int64_t)chunk_id * chunk;
+    const int64_t p_end = min(p_begin + chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     constexpr int kCheck = V < 4 ? V : 4;     // pixels between two looks at the queue fill
@@ -1067,8 +1069,16 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
         if (sum) atomicAdd(&store.below[s0 + threadIdx.x], sum);
     }
     // the work item's histograms are stored -- not added -- so the per-tile stage reads them without a reset
-    uint32_t* hist_out = ws.block_hist + (size_t)item * 512;
-    for (int i = threadIdx.x; i < 512; i += TPB) put(&hist_out[i], (&sh->hist[0][0])[i]);
+    if (g.fine_chunk) {      // small batches, many small work items: one histogram per tile, added to (integers: any order)
+        uint32_t* hist_out = ws.block_hist + (size_t)tile * g.blocks_per_tile * 512;
+        for (int i = threadIdx.x; i < 512; i += TPB) {
+            const uint32_t v = (&sh->hist[0][0])[i];
+            if (v) atomicAdd(&hist_out[i], v);
+        }
+    } else {
+        uint32_t* hist_out = ws.block_hist + (size_t)item * 512;
+        for (int i = threadIdx.x; i < 512; i += TPB) put(&hist_out[i], (&sh->hist[0][0])[i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1077,8 +1087,9 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 template <typename T, typename O, int V, bool kUnit, int TPB, bool kInter>
 __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
                                  const float* __restrict__ stain_matrix) {
-    const int64_t p_begin = (int64_t)chunk_id * kChunk;
-    const int64_t p_end = min(p_begin + (int64_t)kChunk, g.pixels);
+    const int64_t chunk = g.fine_chunk ? g.fine_chunk : kChunk;
+    const int64_t p_begin = (int64_t)chunk_id * chunk;
+    const int64_t p_end = min(p_begin + chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
     O* dst = out + tile * 3 * g.pixels;
     const StageRecord* rec = &ws.state[tile].rec[2];
@@ -1252,6 +1263,10 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
             put(&st.ncand[s], 0u);
         }
     }
+    if (g.fine_chunk) {      // the tile's histogram is added to by many small work items: start from zero
+        uint32_t* row = ws.block_hist + (size_t)group * g.blocks_per_tile * 512;
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) put(&row[i], 0u);
+    }
     if (g.spread) {      // every tile's counters and the group-level sums start from zero
         for (int64_t i = threadIdx.x; i < g.n_tiles * kSlots; i += blockDim.x) {
             put(&ws.state[i / kSlots].below[i % kSlots], 0u);
@@ -1350,7 +1365,7 @@ __device__ __forceinline__ void prefetch_pair(PairPrefetch& pf, const Geometry& 
         pf.scale[j] = get(&rec->bin_scale[j]);
     }
     const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
-    const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
+    const int64_t nblk = g.fine_chunk ? 1 : (g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile);
     const uint32_t* src = ws.block_hist + first * 512 + (threadIdx.x & 511);     // thread owns bin t%256 of slot (t/256)%2 ...
     const int half = (int)threadIdx.x >> 9;                                        // ... for every second work item
 #pragma unroll
@@ -1383,7 +1398,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
         want_in[j] = ok[j] ? (uint32_t)(pf.rank[j] - pf.below[j]) : 0u;
     }
     const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
-    const int64_t nblk = g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile;
+    const int64_t nblk = g.fine_chunk ? 1 : (g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile);
     __syncthreads();      // the scratch reset is visible
     {
         const uint32_t* src = ws.block_hist + first * 512 + (threadIdx.x & 511);
@@ -1685,6 +1700,10 @@ __device__ void stain_stage(const T* __restrict__ images, const Geometry& g, con
         }
         put(&rec->use_all, 1);
     }
+    if (g.fine_chunk) {      // the angle histogram has been consumed (prefetched at the top): clear it for the concentration pass
+        uint32_t* row = ws.block_hist + (size_t)group * g.blocks_per_tile * 512;
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) put(&row[i], 0u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1744,12 +1763,14 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
 template <typename T, int V, bool kConc, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ BracketScratch<kStreamThreads> sh;
-    bracket_item<T, V, kConc, kStreamThreads, kInter>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh);
+    const int per_tile = g.fine_chunk ? g.fine_blocks : g.blocks_per_tile;
+    bracket_item<T, V, kConc, kStreamThreads, kInter>(images, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, blockIdx.x, &sh);
 }
 
 template <typename T, typename O, int V, bool kUnit, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __restrict__ images, O* __restrict__ out, Geometry g, Workspace ws, const float* __restrict__ stain_matrix) {
-    reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, stain_matrix);
+    const int per_tile = g.fine_chunk ? g.fine_blocks : g.blocks_per_tile;
+    reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix);
 }
 
 
@@ -1946,9 +1967,10 @@ static void set_sampling(Geometry& g) {
 template <typename T, int V, bool kInter = false>
 static int run_estimate(const T* images, const Geometry& g, const Workspace& ws, int n_groups, int allow_fallback, const float* tmc, float* he_out, float* max_c_out, hipStream_t stream) {
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
+    const unsigned grid_b = (unsigned)(g.n_tiles * (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile));      // bracket stages
     hipLaunchKernelGGL((stats_kernel<T, V, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((plane_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws, allow_fallback);
-    hipLaunchKernelGGL((bracket_kernel<T, V, false, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL((bracket_kernel<T, V, false, kInter>), dim3(grid_b), dim3(kStreamThreads), 0, stream, images, g, ws);
     if (g.spread) {
         hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)g.n_tiles), dim3(512), 0, stream, g, ws, 0);
         hipLaunchKernelGGL(pool_gather_kernel, dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, g, ws, 0);
@@ -1956,7 +1978,7 @@ static int run_estimate(const T* images, const Geometry& g, const Workspace& ws,
     } else {
         hipLaunchKernelGGL((stain_kernel<T>), dim3(n_groups), dim3(kGroupThreads), 0, stream, images, g, ws);
     }
-    hipLaunchKernelGGL((bracket_kernel<T, V, true, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL((bracket_kernel<T, V, true, kInter>), dim3(grid_b), dim3(kStreamThreads), 0, stream, images, g, ws);
     if (g.spread) {
         hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)g.n_tiles), dim3(512), 0, stream, g, ws, 1);
         hipLaunchKernelGGL(pool_gather_kernel, dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, g, ws, 1);
@@ -1969,7 +1991,7 @@ static int run_estimate(const T* images, const Geometry& g, const Workspace& ws,
 
 template <typename T, typename O, int V, bool kInter = false>
 static int run_transform(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
-    const unsigned items = (unsigned)(g.n_tiles * g.blocks_per_tile);
+    const unsigned items = (unsigned)(g.n_tiles * (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile));
     int rc = run_estimate<T, V, kInter>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
     if (rc != SX_OK) return rc;
     if (unit)
@@ -1988,6 +2010,21 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     const bool vec = (g.pixels % W == 0) && aligned_for(images, 16) && aligned_for(out, out_elem * W);
     g.vec = vec ? 1 : 0;
     set_sampling(g);
+    // Small batches: with 16384-pixel work items a single 512x512 tile is 16 workgroups on 256 CUs and a bracket pass takes
+    // 15 us of pure latency.  The bracket and reconstruct stages (integer counts / independent pixels: the split cannot
+    // change a bit of the result) then use smaller work items -- at least two sweeps of a workgroup, aiming at ~1024 work
+    // items; the moments stage keeps its fixed 16384-pixel grouping so that a tile's covariance has the same bits
+    // whatever batch it arrives in.
+    if (g.n_tiles * (int64_t)g.blocks_per_tile <= 32) {      // (measured: 1 tile 89 -> 78 us, 2 tiles 90 -> 81 us; from 4 tiles on the fixed cost per work item eats the gain)
+        const int64_t floor_px = (int64_t)kStreamThreads * (vec ? W : 1) * 2;
+        int64_t chunk = 2048;
+        while (chunk < floor_px) chunk *= 2;
+        while (chunk * 2 < kChunk && g.n_tiles * ((g.pixels + chunk - 1) / chunk) > 1024) chunk *= 2;
+        if (chunk < kChunk) {
+            g.fine_chunk = (int)chunk;
+            g.fine_blocks = (int)((g.pixels + chunk - 1) / chunk);
+        }
+    }
     const T* in = static_cast<const T*>(images);
     if (g.interleaved) {      // (N,H,W,3): its own instantiations, so the planar kernels carry no trace of it
         if constexpr (sizeof(T) == 1) {
@@ -2189,7 +2226,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -2207,7 +2244,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2234,7 +2271,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2256,7 +2293,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
@@ -2285,7 +2322,7 @@ extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* m
 // distributed pooled fit on the bracket machinery: see include/stainx_hip.h
 // ------------------------------------------------------------------------------------------------
 static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, int sample_count) {
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
     set_sampling(g);                 // local sample stride; cap per tile
     g.spread = 1;                    // also for a single local tile: the group spans other ranks
     g.cap = cap_for(g.pixels);
@@ -2297,7 +2334,7 @@ static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, 
 
 extern "C" int sx_macenko_pfit_sample_count(int64_t n, int64_t h, int64_t w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
     set_sampling(g);
     return g.sample_count;
 }
