@@ -44,7 +44,19 @@ for case in range(cases):
     scale = 1.0 if unit else 255.0
     tol = {torch.uint8: (1.0 if not unit else 1.0 / 255), torch.float16: 0.26 * scale / 255 * 4, torch.bfloat16: 2.1 * scale / 255 * 4, torch.float32: 2.55e-2 * scale / 255,
            torch.float64: 2.55e-2 * scale / 255}[dt]
-    err = float(np.abs(got.astype(np.float64) - np.asarray(want, dtype=np.float64)).max())
+    # a tile whose two small covariance eigenvalues nearly coincide has no stable stain plane (in the reference either): its
+    # middle eigenvector, and with it the output, moves with the last bits of the covariance -- such tiles are counted, not compared
+    x_f = x.float().numpy() if dt == torch.bfloat16 else x.numpy()
+    stable = np.ones(n, dtype=bool)
+    for i in range(n):
+        rows = so.optical_density(so.to_unit_float(x_f[i:i + 1]))[0].reshape(3, -1).T.astype(np.float64)
+        kept = rows[rows.min(1) >= so.BETA]
+        lam = np.linalg.eigvalsh(np.cov((kept if kept.shape[0] >= 3 else rows).T))
+        stable[i] = (lam[1] - lam[0]) >= 1e-3 * lam[2]
+    worst["ill-conditioned tiles skipped"] = worst.get("ill-conditioned tiles skipped", 0) + int((~stable).sum())
+    if not stable.any():
+        continue
+    err = float(np.abs(got.astype(np.float64) - np.asarray(want, dtype=np.float64))[stable].max())
     worst[dt] = max(worst.get(dt, 0.0), err / tol)
     p = be.tile_params(n)
     if err > tol:
