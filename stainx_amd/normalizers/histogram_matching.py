@@ -1,4 +1,4 @@
-"""Histogram-matching normaliser (mirrors reference normalizers/histogram_matching.py)."""
+"""Histogram matching against a reference image (API of stainx.HistogramMatching, incl. ``channel_axis``)."""
 from __future__ import annotations
 
 from typing import Any
@@ -7,29 +7,21 @@ from stainx_amd.normalizers._template import NormalizerTemplate
 
 
 class HistogramMatching(NormalizerTemplate):
+    engine = "HistogramMatchingHIP"
+    # three normalised 256-bin histograms (one per channel); `_reference_histogram` is the first of them, `_ref_vals` /
+    # `_ref_cdf` exist for attribute compatibility with the reference and stay unset (its transform never reads them)
+    fitted_slots = ("_ref_histograms_256", "_reference_histogram", "_ref_vals", "_ref_cdf")
+
     def __init__(self, device: Any | None = None, backend: str | None = None, channel_axis: int = 1):
         self.channel_axis = channel_axis
         super().__init__(device=device, backend=backend)
 
-    def _init_algorithm_attributes(self):
-        self._reference_histogram = None
-        self._ref_vals = None
-        self._ref_cdf = None
-        self._ref_histograms_256 = None
-
-    def _get_torch_hip_class(self):
-        from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
-
-        return HistogramMatchingHIP
-
-    def _get_backend_kwargs(self) -> dict:
+    def engine_options(self) -> dict:
         return {"channel_axis": self.channel_axis}
 
-    def _compute_reference_params(self, images: Any) -> None:
-        self._ref_histograms_256 = self._get_backend_impl().compute_reference_histograms(images)
-        self._reference_histogram = self._ref_histograms_256[0]
+    def learn(self, engine, images):
+        per_channel = engine.compute_reference_histograms(images)
+        return per_channel, per_channel[0], None, None
 
-    def _get_reference_params(self) -> tuple:
-        if self._ref_histograms_256:
-            return (self._ref_histograms_256,)
-        return (self._reference_histogram,)
+    def arguments(self) -> tuple:
+        return (self._ref_histograms_256 if self._ref_histograms_256 else self._reference_histogram,)

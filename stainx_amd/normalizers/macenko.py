@@ -1,4 +1,4 @@
-"""Macenko normaliser (mirrors reference normalizers/macenko.py:11-73)."""
+"""Macenko stain normalisation (API of stainx.Macenko, incl. ``normalize_to_0_1`` and ``precision``)."""
 from __future__ import annotations
 
 from typing import Any
@@ -7,8 +7,11 @@ from stainx_amd.normalizers._template import NormalizerTemplate
 
 
 class Macenko(NormalizerTemplate):
-    """``normalize_to_0_1`` defaults to False here (output ~[0,255]); ``StainNormalizerTransform``
-    defaults it to True.  ``precision`` is validated like the reference's (macenko.py:35-44)."""
+    """``normalize_to_0_1`` defaults to False here (output ~[0,255]); ``StainNormalizerTransform`` defaults it to True.
+    ``precision`` takes the reference's two values; both select the same kernels (fp64 covariance, fp32 pixels)."""
+
+    engine = "MacenkoHIP"
+    fitted_slots = ("_stain_matrix", "_target_max_conc", "_concentration_matrix")      # (3,2), (2,), unused
 
     def __init__(self, device: Any | None = None, backend: str | None = None, normalize_to_0_1: bool = False, precision: str = "stable"):
         if precision not in ("stable", "fast"):
@@ -17,26 +20,16 @@ class Macenko(NormalizerTemplate):
         self.normalize_to_0_1 = normalize_to_0_1
         super().__init__(device=device, backend=backend)
 
-    def _init_algorithm_attributes(self):
-        self._stain_matrix = None
-        self._concentration_matrix = None
-        self._target_max_conc = None
+    def engine_options(self) -> dict:
+        return {} if self._precision == "stable" else {"precision": self._precision}
 
-    def _get_torch_hip_class(self):
-        from stainx_amd.backends.torch_hip_backend import MacenkoHIP
+    def learn(self, engine, images):
+        stain_matrix, max_conc = engine.compute_reference_stain_matrix(images)
+        return stain_matrix, max_conc, None
 
-        return MacenkoHIP
-
-    def _get_backend_kwargs(self) -> dict:
-        return {"precision": self._precision} if self._precision != "stable" else {}
-
-    def _compute_reference_params(self, images: Any) -> None:
-        self._stain_matrix, self._target_max_conc = self._get_backend_impl().compute_reference_stain_matrix(images)
-        self._concentration_matrix = None
-
-    def _get_reference_params(self) -> tuple:
+    def arguments(self) -> tuple:
         return (self._stain_matrix, self._target_max_conc)
 
-    def _run_transform(self, impl, images, params):
-        # `/255` after the cast to the input dtype (_template.py:111-112) is fused into the last kernel
-        return impl.transform(images, *params, normalize_to_0_1=bool(self.normalize_to_0_1))
+    def call_options(self) -> dict:
+        # the `/255` after the cast to the input dtype is fused into the last kernel
+        return {"normalize_to_0_1": bool(self.normalize_to_0_1)}

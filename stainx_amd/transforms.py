@@ -111,7 +111,7 @@ class StainNormalizerTransform(nn.Module):
         if current.type == device.type and (current.index is None or device.index is None or current.index == device.index):
             return
         self.normalizer.device = device
-        self.normalizer._backend_impl = None
+        self.normalizer._engine = None
         for name in _FIT_TENSOR_ATTRS:
             value = getattr(self.normalizer, name, None)
             if isinstance(value, torch.Tensor):

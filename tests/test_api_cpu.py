@@ -56,7 +56,7 @@ def test_backend_ids():
         Reinhard(backend="torch")
     with pytest.raises(ValueError, match="precision must be"):
         Macenko(precision="ultra")
-    assert Macenko(device="cuda", precision="fast")._get_backend_kwargs() == {"precision": "fast"}
+    assert Macenko(device="cuda", precision="fast").engine_options() == {"precision": "fast"}
 
 
 def test_no_cpu_fallback():
