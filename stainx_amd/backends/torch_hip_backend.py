@@ -54,8 +54,9 @@ class MacenkoHIP(TorchHIPBackendBase):
         super().__init__(device)
         if precision not in ("stable", "fast"):
             raise ValueError(f"precision must be 'stable' or 'fast', got {precision!r}")
-        # One numerical path: fp64 covariance + fp32 pixels.  "fast" is accepted for API parity
-        # (torch_cuda_backend.py:114-118) and currently selects the same kernels.
+        # "stable": exact nearest-rank percentiles (the parity path).  "fast" (the reference has one too,
+        # torch_cuda_backend.py:114-118): the percentiles of a 4096-pixel sample of each tile stand in for the exact ones --
+        # moments pass + one per-tile stage + reconstruct instead of four passes and three stages.  The fit is always exact.
         self._precision = precision
         self.last_workspace: torch.Tensor | None = None
 
@@ -92,7 +93,8 @@ class MacenkoHIP(TorchHIPBackendBase):
         with torch.cuda.device(self.device):
             nbytes = self._lib.sx_macenko_workspace_bytes(n, h, w)
             ws = self._scratch.get(nbytes, self.device)
-            flags = (_native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0) | (_native.MACENKO_CHANNELS_LAST if channels_last else 0)
+            flags = ((_native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0) | (_native.MACENKO_CHANNELS_LAST if channels_last else 0)
+                     | (_native.MACENKO_FAST if self._precision == "fast" else 0))
             rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),
                                                 flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_transform")

@@ -90,6 +90,7 @@ struct Geometry {
     int distributed;              // 1: the group also spans other ranks (sx_macenko_pfit_*): totals come from the host, no local fallback
     long long n_all;              // distributed: pixels of the whole group over all ranks
     int fine_chunk, fine_blocks;  // small batches: pixels per work item / work items per tile of the bracket and reconstruct stages (0: kChunk)
+    int fast;                     // precision="fast": sample percentiles instead of the exact ones
 };
 
 // Pooled fit over several tiles ("spread" mode): the streaming stages keep candidates, counters and histograms per
@@ -655,7 +656,7 @@ __device__ uint32_t radix_select_stream(unsigned long long count, unsigned long 
 // are listed and the exact element found by rank counting (a crowded bin falls back to radix rounds).  Outputs
 // per bracket: the bracket keys and the (origin, scale) of the bracket-relative bins used for the candidates.
 // Needs reset_scratch() and a barrier before it; five barriers inside.
-template <int kSets>
+template <int kSets, bool kPoint = false>
 __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kKeys], unsigned long long n_total, const unsigned long long (&k0)[2], uint32_t (&lo)[2],
                                 uint32_t (&hi)[2], double (&bin_origin)[2], double (&bin_scale)[2]) {
     const uint32_t lane = lane_id();
@@ -709,7 +710,13 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
     // by the count check and repaired by the slow path.
     auto rank_of = [&](int q) -> uint32_t {
         long long lo_r, hi_r;
-        bracket_ranks(m_valid, n_total, (q >> 1) ? k0[1] : k0[0], lo_r, hi_r);
+        if constexpr (kPoint) {      // precision="fast": the sample's own order statistic at the matching rank, no bracket
+            const unsigned long long k = (q >> 1) ? k0[1] : k0[0];
+            const float f = n_total > 1 ? (float)k * __builtin_amdgcn_rcpf((float)(n_total - 1)) : 0.0f;
+            lo_r = hi_r = (long long)rintf(f * (float)(m_valid - 1));
+        } else {
+            bracket_ranks(m_valid, n_total, (q >> 1) ? k0[1] : k0[0], lo_r, hi_r);
+        }
         return (uint32_t)min(max((q & 1) ? hi_r : lo_r, 0ll), (long long)m_valid - 1);
     };
     uint32_t bin[kSets][kKeys];
@@ -1201,8 +1208,9 @@ __device__ void all_pixel_moments(const T* __restrict__ images, const Geometry& 
     __syncthreads();
 }
 
-template <typename T>
-__device__ void plane_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int allow_fallback, TileScratch* sh, const double* __restrict__ given_moments = nullptr) {
+template <typename T, bool kFast = false>
+__device__ void plane_stage(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int allow_fallback, TileScratch* sh, const double* __restrict__ given_moments = nullptr,
+                            const float* __restrict__ target_max_conc = nullptr) {
     GroupState& st = ws.state[group];
     SX_STAMP(st, 0);
     reset_scratch(sh);
@@ -1296,6 +1304,63 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
     const unsigned long long k0[2] = {nearest_rank_index(1.0, n_sel), nearest_rank_index(99.0, n_sel)};   // alpha = 1 (torch_backend.py:421-422)
     uint32_t lo[2], hi[2];
     double origin[2], scale[2];
+    if constexpr (kFast) {
+        // precision="fast" (reference: Macenko(precision="fast"), a relaxed-accuracy path): the percentiles of the
+        // 4096-pixel sample stand in for the percentiles of the tile, so the two bracket passes and two of the three
+        // per-tile stages disappear -- moments pass, this stage, reconstruct.
+        sample_brackets<1, true>(sh, key, n_sel, k0, lo, hi, origin, scale);
+        if (threadIdx.x == 0) {
+            float he[6], pinv[6];
+            stain_vectors_and_pinv(v, lo[0], lo[1], he, pinv);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                put(&st.he[i], he[i]);
+                put(&st.pinv[i], pinv[i]);
+                sh->coef[i] = pinv[i];
+            }
+            put(&st.phi_key[0], lo[0]);
+            put(&st.phi_key[1], lo[1]);
+        }
+        __syncthreads();
+        reset_scratch(sh);
+        float pinv[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pinv[i] = sh->coef[i];
+        __syncthreads();
+        uint32_t ckey[2][kKeys];
+#pragma unroll
+        for (int i = 0; i < kKeys; ++i) {
+            const int j = i * kGroupThreads + (int)threadIdx.x;
+            uint32_t ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;
+            if (j < g.sample_count) {
+                float c0, c1;
+                concentration(sod[i], pinv, c0, c1);
+                ka = float_key(c0);
+                kb = float_key(c1);
+            }
+            ckey[0][i] = ka;
+            ckey[1][i] = kb;
+            sh->keys[0][j] = ka;
+            sh->keys[1][j] = kb;
+        }
+        const unsigned long long n_all = (unsigned long long)group_pixels(g, group).count;
+        const unsigned long long k99 = nearest_rank_index(99.0, n_all);
+        const unsigned long long kc[2] = {k99, k99};
+        sample_brackets<2, true>(sh, ckey, n_all, kc, lo, hi, origin, scale);
+        if (threadIdx.x == 0) {
+            const float m0 = key_float(lo[0]), m1 = key_float(lo[1]);
+            put(&st.max_c[0], m0);
+            put(&st.max_c[1], m1);
+            StageRecord* rec = &st.rec[2];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) put(&rec->coef[i], pinv[i]);
+            put(&rec->scale[0], target_max_conc[0] / m0);
+            put(&rec->scale[1], target_max_conc[1] / m1);
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) put(&st.ncand_seen[s], 0u);
+        }
+        return;
+    }
     sample_brackets<1>(sh, key, n_sel, k0, lo, hi, origin, scale);
     SX_STAMP(st, 4);
     if (threadIdx.x == 0) {
@@ -1775,6 +1840,12 @@ __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __
 
 
 template <typename T>
+__global__ __launch_bounds__(kGroupThreads) void fast_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc) {
+    __shared__ TileScratch sh;
+    plane_stage<T, true>(images, g, ws, blockIdx.x, 1, &sh, nullptr, target_max_conc);
+}
+
+template <typename T>
 __global__ __launch_bounds__(kGroupThreads) void plane_kernel(const T* __restrict__ images, Geometry g, Workspace ws, int allow_fallback) {
     __shared__ TileScratch sh;
     plane_stage<T>(images, g, ws, blockIdx.x, allow_fallback, &sh);
@@ -1992,7 +2063,14 @@ static int run_estimate(const T* images, const Geometry& g, const Workspace& ws,
 template <typename T, typename O, int V, bool kInter = false>
 static int run_transform(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
     const unsigned items = (unsigned)(g.n_tiles * (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile));
-    int rc = run_estimate<T, V, kInter>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
+    int rc = SX_OK;
+    if (g.fast) {
+        hipLaunchKernelGGL((stats_kernel<T, V, kInter>), dim3((unsigned)(g.n_tiles * g.blocks_per_tile)), dim3(kStreamThreads), 0, stream, images, g, ws);
+        hipLaunchKernelGGL((fast_kernel<T>), dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
+        rc = check_launch("macenko fast estimate");
+    } else {
+        rc = run_estimate<T, V, kInter>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
+    }
     if (rc != SX_OK) return rc;
     if (unit)
         hipLaunchKernelGGL((reconstruct_kernel<T, O, V, true, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
@@ -2226,7 +2304,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0, (flags & SX_MACENKO_FAST) ? 1 : 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -2244,7 +2322,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2271,7 +2349,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2293,7 +2371,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
@@ -2322,7 +2400,7 @@ extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* m
 // distributed pooled fit on the bracket machinery: see include/stainx_hip.h
 // ------------------------------------------------------------------------------------------------
 static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, int sample_count) {
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
     set_sampling(g);                 // local sample stride; cap per tile
     g.spread = 1;                    // also for a single local tile: the group spans other ranks
     g.cap = cap_for(g.pixels);
@@ -2334,7 +2412,7 @@ static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, 
 
 extern "C" int sx_macenko_pfit_sample_count(int64_t n, int64_t h, int64_t w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
     set_sampling(g);
     return g.sample_count;
 }

@@ -323,3 +323,25 @@ def test_big_batch_equals_its_pieces(dev):
         assert torch.equal(out[lo:hi], part)
         p = be.tile_params(hi - lo)
         assert torch.equal(params["he"][lo:hi], p["he"]) and torch.equal(params["max_c"][lo:hi], p["max_c"])
+
+
+def test_precision_fast_is_a_sampled_estimate(dev):
+    """Macenko(precision="fast"): per-tile percentiles from the 4096-pixel sample (two passes instead of four).  Not a
+    parity path -- the reference's own fast mode is a relaxed-accuracy one too -- so the check is statistical: close to
+    the exact transform (mean abs error below one grey level per tile), same shape/dtype, deterministic."""
+    from stainx_amd import Macenko
+
+    ref = synth.reference_tile(128, 128).to(dev)
+    x = synth.as_dtype(synth.he_batch(6, 256, 256, seed0=5100), torch.float32).to(dev)
+    exact = Macenko(device=dev).fit(ref).transform(x)
+    fast_norm = Macenko(device=dev, precision="fast").fit(ref)
+    fast = fast_norm.transform(x)
+    assert fast.shape == exact.shape and fast.dtype == exact.dtype
+    err = (fast - exact).abs().reshape(6, -1)
+    assert float(err.mean(1).max()) < 1.0, err.mean(1)
+    assert float(err.max()) < 12.0
+    assert torch.equal(fast, fast_norm.transform(x))
+    for dt in ("u8", "bf16"):
+        xi = synth.as_dtype(synth.he_batch(2, 64, 96, seed0=5200), TORCH_DTYPES[dt]).to(dev)
+        out = fast_norm.transform(xi)
+        assert out.dtype == xi.dtype and out.shape == xi.shape
