@@ -79,10 +79,15 @@ def measured_traffic():
 
 def main() -> None:
     args = parse()
+    # Only the result line may reach stdout: libraries underneath print there (RCCL's version banner at communicator
+    # creation, for one), so file descriptor 1 points at stderr until the line is written.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("STAINX_BENCH_FORCE_DIST"))      # (the env switch lets a one-GPU box run the RCCL code path)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -160,7 +165,10 @@ def main() -> None:
 
             want = so.macenko_transform(x_cpu[:2].numpy(), he, max_c)
             line["max_abs_vs_oracle_0_255"] = float((out[:2].cpu() - torch.from_numpy(want)).abs().max())
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
