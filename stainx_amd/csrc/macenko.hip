@@ -1544,18 +1544,18 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
         scan_pick32(sh->hist_c[wave], second ? want_in[1] : want_in[0], b, rb);
         if (lane_id() == 0) {
             sh->rank_in_bin_c[wave] = rb;
-            bin_key_range(b, second ? pf.origin[1] : pf.origin[0], second ? pf.scale[1] : pf.scale[0], sh->range_c[wave][0], sh->range_c[wave][1]);
+            sh->range_c[wave][0] = b;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (!ok[j]) continue;
-        const uint32_t k_first = sh->range_c[j][0], k_last = sh->range_c[j][1], n = pf.ncand[j];
+        const uint32_t b = sh->range_c[j][0], n = pf.ncand[j];
 #pragma unroll
         for (int u = 0; u < kPrefetchCand; ++u) {
             const uint32_t idx = u * kGroupThreads + threadIdx.x, k = pf.cand[j][u];
-            if (idx < n && k >= k_first && k <= k_last) {
+            if (idx < n && bin_of(k, pf.origin[j], pf.scale[j]) == b) {
                 const uint32_t at = atomicAdd(&sh->count_c[j], 1u);
                 if (at < (uint32_t)kShortList) sh->list_c[j][at] = k;
             }
@@ -1572,7 +1572,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const uint32_t idx = base + u * kGroupThreads;
-                if (idx < n && k[u] >= k_first && k[u] <= k_last) {
+                if (idx < n && bin_of(k[u], pf.origin[j], pf.scale[j]) == b) {
                     const uint32_t at = atomicAdd(&sh->count_c[j], 1u);
                     if (at < (uint32_t)kShortList) sh->list_c[j][at] = k[u];
                 }
