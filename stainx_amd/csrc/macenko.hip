@@ -91,6 +91,8 @@ struct Geometry {
     long long n_all;              // distributed: pixels of the whole group over all ranks
     int fine_chunk, fine_blocks;  // small batches: pixels per work item / work items per tile of the bracket and reconstruct stages (0: kChunk)
     int fast;                     // precision="fast": sample percentiles instead of the exact ones
+    int chunk;                    // pixels per work item: the tile split evenly over its blocks_per_tile work items (<= kChunk)
+    int vec_width;                // pixels per 16-byte pack of the element type (host side, for the chunk rounding)
 };
 
 // Pooled fit over several tiles ("spread" mode): the streaming stages keep candidates, counters and histograms per
@@ -884,8 +886,8 @@ template <int TPB> struct StatsScratch {
 
 template <typename T, int V, int TPB, bool kInter>
 __device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh) {
-    const int64_t p_begin = (int64_t)chunk_id * kChunk;
-    const int64_t p_end = min(p_begin + (int64_t)kChunk, g.pixels);
+    const int64_t p_begin = (int64_t)chunk_id * g.chunk;
+    const int64_t p_end = min(p_begin + (int64_t)g.chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
     const int group = g.pooled ? 0 : (int)tile;
     float* sample_out = ws.sample_od + (size_t)group * 3 * kSample;
@@ -1020,7 +1022,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
     const int group = g.pooled ? 0 : (int)tile;
     GroupState& st = ws.state[group];
     constexpr int s0 = kConc ? 2 : 0;
-    const int64_t chunk = g.fine_chunk ? g.fine_chunk : kChunk;
+    const int64_t chunk = g.fine_chunk ? g.fine_chunk : g.chunk;
     const int64_t p_begin = (int64_t)chunk_id * chunk;
     const int64_t p_end = min(p_begin + chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
@@ -1155,7 +1157,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 template <typename T, typename O, int V, bool kUnit, int TPB, bool kInter>
 __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
                                  const float* __restrict__ stain_matrix) {
-    const int64_t chunk = g.fine_chunk ? g.fine_chunk : kChunk;
+    const int64_t chunk = g.fine_chunk ? g.fine_chunk : g.chunk;
     const int64_t p_begin = (int64_t)chunk_id * chunk;
     const int64_t p_end = min(p_begin + chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
@@ -1984,7 +1986,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(kStreamThreads) void dfit_histogram_kernel(const T* __restrict__ images, Geometry g, const DFitState* __restrict__ st, int stage, unsigned long long* __restrict__ hist) {
     const int64_t tile = blockIdx.x / g.blocks_per_tile;
     const int chunk_id = blockIdx.x % g.blocks_per_tile;
-    const int64_t p_begin = (int64_t)chunk_id * kChunk, p_end = min(p_begin + (int64_t)kChunk, g.pixels);
+    const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + (int64_t)g.chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
     __shared__ uint32_t local[2][256];
     for (int i = threadIdx.x; i < 512; i += kStreamThreads) (&local[0][0])[i] = 0;
@@ -2086,6 +2088,15 @@ __global__ void export_params_kernel(const GroupState* __restrict__ state, int64
 // ------------------------------------------------------------------------------------------------
 static bool aligned_for(const void* p, size_t bytes) { return (reinterpret_cast<uintptr_t>(p) % bytes) == 0; }
 
+// The tile split evenly over its work items (a 224x224 tile is 3 x 16384 + 1024 pixels otherwise: a quarter of the
+// workgroups nearly idle); a function of the tile size and the element type's pack only, so a tile's partial sums are
+// grouped the same way whatever batch -- or entry point -- it arrives through.
+static void set_chunk(Geometry& g) {
+    const int64_t unit = (int64_t)kStreamThreads * (g.vec ? g.vec_width : 1);
+    const int64_t even = (g.pixels + g.blocks_per_tile - 1) / g.blocks_per_tile;
+    g.chunk = (int)std::min<int64_t>(kChunk, (even + unit - 1) / unit * unit);
+}
+
 static void set_sampling(Geometry& g) {
     const int64_t count = g.pooled ? g.n_tiles * g.pixels : g.pixels;
     int64_t stride = 1;                                   // smallest power of two with ceil(count/stride) <= kSample
@@ -2093,6 +2104,7 @@ static void set_sampling(Geometry& g) {
     g.sample_stride = (int)stride;
     g.sample_count = (int)std::min<int64_t>(kSample, (count + stride - 1) / stride);
     g.spread = (g.pooled && g.n_tiles > 1) ? 1 : 0;
+    set_chunk(g);
     g.cap = cap_for(g.spread ? g.pixels : count);
 }
 
@@ -2148,6 +2160,7 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     constexpr int W = PackOf<T>::n;
     const bool vec = (g.pixels % W == 0) && aligned_for(images, 16) && aligned_for(out, out_elem * W);
     g.vec = vec ? 1 : 0;
+    g.vec_width = W;
     set_sampling(g);
     // Small batches: with 16384-pixel work items a single 512x512 tile is 16 workgroups on 256 CUs and a bracket pass takes
     // 15 us of pure latency.  The bracket and reconstruct stages (integer counts / independent pixels: the split cannot
@@ -2191,6 +2204,7 @@ static int fit_typed(const void* images, const Geometry& g0, const Workspace& ws
     constexpr int W = PackOf<T>::n;
     const bool vec = (g.pixels % W == 0) && aligned_for(images, 16);
     g.vec = vec ? 1 : 0;
+    g.vec_width = W;
     set_sampling(g);
     const T* in = static_cast<const T*>(images);
     return vec ? run_estimate<T, W>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream)
@@ -2289,6 +2303,7 @@ static int dfit_moments_typed(const void* images, const Geometry& g0, const Work
     constexpr int W = PackOf<T>::n;
     const bool vec = (g.pixels % W == 0) && aligned_for(images, 16);
     g.vec = vec ? 1 : 0;
+    g.vec_width = W;
     set_sampling(g);
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
@@ -2322,6 +2337,8 @@ static int pfit_pass_typed(const void* images, const Geometry& g0, const Workspa
     constexpr int W = PackOf<T>::n;
     const bool vec = (g.pixels % W == 0) && aligned_for(images, 16);
     g.vec = vec ? 1 : 0;
+    g.vec_width = W;
+    set_chunk(g);
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
     if (stage < 0) {      // stats
@@ -2365,7 +2382,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0, (flags & SX_MACENKO_FAST) ? 1 : 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0, (flags & SX_MACENKO_FAST) ? 1 : 0, kChunk, 1};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -2383,7 +2400,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2410,7 +2427,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2432,7 +2449,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
@@ -2461,7 +2478,7 @@ extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* m
 // distributed pooled fit on the bracket machinery: see include/stainx_hip.h
 // ------------------------------------------------------------------------------------------------
 static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, int sample_count) {
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
     set_sampling(g);                 // local sample stride; cap per tile
     g.spread = 1;                    // also for a single local tile: the group spans other ranks
     g.cap = cap_for(g.pixels);
@@ -2473,7 +2490,7 @@ static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, 
 
 extern "C" int sx_macenko_pfit_sample_count(int64_t n, int64_t h, int64_t w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
     set_sampling(g);
     return g.sample_count;
 }
