@@ -20,6 +20,7 @@ SX_OK, SX_ERR_BAD_ARG, SX_ERR_DTYPE, SX_ERR_WORKSPACE, SX_ERR_LAUNCH = range(5)
 MACENKO_NORMALIZE_0_1 = 1
 MACENKO_CHANNELS_LAST = 2
 MACENKO_FAST = 4
+MACENKO_NO_TIE_SHORTCUT = 8
 MACENKO_PARAM_FLOATS = 48
 PFIT_SUMS = 1033
 PFIT_COMPACT = 32768

@@ -68,7 +68,7 @@ class MacenkoHIP(TorchHIPBackendBase):
             raise ValueError(f"Macenko {what} expects 3 channels in dim 1 (NCHW), got C={images.shape[1]} with shape {tuple(images.shape)}")
 
     def transform(self, images: torch.Tensor, stain_matrix: torch.Tensor, target_max_conc: torch.Tensor, *, normalize_to_0_1: bool = False,
-                  channels_last: bool = False) -> torch.Tensor:
+                  channels_last: bool = False, _extra_flags: int = 0) -> torch.Tensor:
         """``channels_last=True`` (an extension; the reference takes NCHW only): ``images`` is (N,H,W,3) as decoders and PIL
         hand tiles over, and so is the result -- the permute + copy a caller would otherwise do first is fused away."""
         images = images.to(self.device)
@@ -94,7 +94,7 @@ class MacenkoHIP(TorchHIPBackendBase):
             nbytes = self._lib.sx_macenko_workspace_bytes(n, h, w)
             ws = self._scratch.get(nbytes, self.device)
             flags = ((_native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0) | (_native.MACENKO_CHANNELS_LAST if channels_last else 0)
-                     | (_native.MACENKO_FAST if self._precision == "fast" else 0))
+                     | (_native.MACENKO_FAST if self._precision == "fast" else 0) | int(_extra_flags))
             rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),
                                                 flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_transform")

@@ -93,6 +93,7 @@ struct Geometry {
     int fast;                     // precision="fast": sample percentiles instead of the exact ones
     int chunk;                    // pixels per work item: the tile split evenly over its blocks_per_tile work items (<= kChunk)
     int vec_width;                // pixels per 16-byte pack of the element type (host side, for the chunk rounding)
+    int no_tie;                   // diagnostic (SX_MACENKO_NO_TIE_SHORTCUT): never resolve a closed bracket from its counts alone
 };
 
 // Pooled fit over several tiles ("spread" mode): the streaming stages keep candidates, counters and histograms per
@@ -1473,7 +1474,7 @@ __device__ uint32_t select_whole_group(const T* __restrict__ images, const Geome
 // histograms and the first 8192 candidates of each slot (loaded before ncand is known: the buffer is always at
 // least kMinCap long, entries beyond ncand are ignored later).
 struct PairPrefetch {
-    uint32_t ncand[2], below[2];
+    uint32_t ncand[2], below[2], lo[2], hi[2];
     unsigned long long rank[2];
     double origin[2], scale[2];
     uint32_t hist[kPrefetchHist];
@@ -1491,6 +1492,8 @@ __device__ __forceinline__ void prefetch_pair(PairPrefetch& pf, const Geometry& 
         pf.rank[j] = get(&st.rank[slot]);
         pf.origin[j] = get(&rec->bin_origin[j]);
         pf.scale[j] = get(&rec->bin_scale[j]);
+        pf.lo[j] = get(&rec->lo[j]);
+        pf.hi[j] = get(&rec->hi[j]);
     }
     const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
     const int64_t nblk = g.fine_chunk ? 1 : (g.pooled ? g.n_tiles * g.blocks_per_tile : g.blocks_per_tile);
@@ -1518,11 +1521,16 @@ template <typename T>
 __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int group, int first_slot, const float* coef, bool use_all,
                              const PairPrefetch& pf, uint32_t (&key_out)[2], TileScratch* sh) {
     GroupState& st = ws.state[group];
-    bool ok[2];
+    bool ok[2], tie[2];
     uint32_t want_in[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        ok[j] = pf.ncand[j] <= g.cap && pf.rank[j] >= pf.below[j] && pf.rank[j] - pf.below[j] < pf.ncand[j];
+        // A bracket that closed on a single key (lo == hi: the sample's order statistics around the wanted rank are one
+        // tie group -- blank or flat tiles, few-colour images) needs no candidates at all: every key counted inside it is
+        // that key, so the counts alone say whether it is the answer.  Without this such a tile overflows its candidate
+        // buffer and one workgroup radix-selects over the whole tile (9 ms for a 1024x1024 tile against 0.1 ms).
+        tie[j] = !g.no_tie && pf.lo[j] == pf.hi[j] && pf.rank[j] >= pf.below[j] && pf.rank[j] - pf.below[j] < pf.ncand[j];
+        ok[j] = !tie[j] && pf.ncand[j] <= g.cap && pf.rank[j] >= pf.below[j] && pf.rank[j] - pf.below[j] < pf.ncand[j];
         want_in[j] = ok[j] ? (uint32_t)(pf.rank[j] - pf.below[j]) : 0u;
     }
     const int64_t first = g.pooled ? 0 : (int64_t)group * g.blocks_per_tile;
@@ -1592,6 +1600,8 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
         const int slot = first_slot + j;
         if (__builtin_expect(ok[j] && sh->count_c[j] <= (uint32_t)kShortList, 1)) {
             key_out[j] = sh->result_c[j];
+        } else if (tie[j]) {
+            key_out[j] = pf.lo[j];
         } else if (ok[j]) {      // crowded bin: radix rounds over the candidates
             const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * g.cap;
             if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
@@ -2382,7 +2392,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0, (flags & SX_MACENKO_FAST) ? 1 : 0, kChunk, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0, (flags & SX_MACENKO_FAST) ? 1 : 0, kChunk, 1, (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -2400,7 +2410,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2427,7 +2437,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2449,7 +2459,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
@@ -2478,7 +2488,7 @@ extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* m
 // distributed pooled fit on the bracket machinery: see include/stainx_hip.h
 // ------------------------------------------------------------------------------------------------
 static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, int sample_count) {
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
     set_sampling(g);                 // local sample stride; cap per tile
     g.spread = 1;                    // also for a single local tile: the group spans other ranks
     g.cap = cap_for(g.pixels);
@@ -2490,7 +2500,7 @@ static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, 
 
 extern "C" int sx_macenko_pfit_sample_count(int64_t n, int64_t h, int64_t w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
     set_sampling(g);
     return g.sample_count;
 }

@@ -163,10 +163,16 @@ def test_bracket_fallback_path_is_exact(dev):
     # 8 distinct pixels, 131072 copies each: every inclusive bracket holds a whole tie group larger than the
     # candidate buffer of a 1024x1024 tile (65536 keys)
     blocky = tile[:, :, ::512, ::256].repeat_interleave(512, dim=2).repeat_interleave(256, dim=3).contiguous()
+    from stainx_amd import _native
+
     for x in (blocky, synth.as_dtype(blocky, torch.float32)):
-        out = be.transform(x.to(dev), torch.from_numpy(ref_he), torch.from_numpy(ref_mc))
+        # (the tie shortcut would resolve these brackets from their counts: switched off to reach the slow path)
+        out = be.transform(x.to(dev), torch.from_numpy(ref_he), torch.from_numpy(ref_mc), _extra_flags=_native.MACENKO_NO_TIE_SHORTCUT)
         p = be.tile_params(1)
         assert int(p["fell_back"][0]) == 0b1111, "expected the full-tile radix select to run for all four slots"
+        fast_out = be.transform(x.to(dev), torch.from_numpy(ref_he), torch.from_numpy(ref_mc))
+        assert int(be.tile_params(1)["fell_back"][0]) == 0, "a bracket closed on one tie group resolves from its counts"
+        assert torch.equal(fast_out, out)
         want, params = so.macenko_transform(x.numpy(), ref_he, ref_mc, return_params=True)
         diff = np.abs(out.cpu().numpy().astype(np.float64) - want.astype(np.float64)).max()
         assert diff <= (1 if x.dtype == torch.uint8 else TOL_255), diff
