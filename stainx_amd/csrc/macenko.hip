@@ -24,6 +24,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace sx {
@@ -114,6 +115,7 @@ struct alignas(256) PoolState {
 struct Workspace {
     GroupState* state;
     double* partial;              // [n_tiles*blocks_per_tile][kPartial]
+    double* partial_all;          // same shape: moments of ALL pixels, written only by work items without kept pixels
     uint32_t* cand;               // [groups][kSlots][cap]
     uint32_t* block_hist;         // [n_tiles*blocks_per_tile][2][256] bracket-relative histograms of a stage's candidates
     float* sample_od;             // [groups][3][kSample] optical density of the strided sample
@@ -139,7 +141,7 @@ static size_t cand_words(int64_t n_tiles, int64_t pixels) {
 static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
     const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
     size_t total = align_up(sizeof(GroupState) * n, 256);
-    total += align_up(sizeof(double) * kPartial * b * n, 256);
+    total += 2 * align_up(sizeof(double) * kPartial * b * n, 256);
     total += align_up(sizeof(uint32_t) * cand_words(n_tiles, pixels), 256);
     total += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     total += align_up(sizeof(float) * 3 * kSample * n, 256);
@@ -154,6 +156,8 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     w.state = reinterpret_cast<GroupState*>(p);
     p += align_up(sizeof(GroupState) * n, 256);
     w.partial = reinterpret_cast<double*>(p);
+    p += align_up(sizeof(double) * kPartial * b * n, 256);
+    w.partial_all = reinterpret_cast<double*>(p);
     p += align_up(sizeof(double) * kPartial * b * n, 256);
     w.cand = reinterpret_cast<uint32_t*>(p);
     p += align_up(sizeof(uint32_t) * cand_words(n_tiles, pixels), 256);
@@ -769,9 +773,7 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
     }
     // Sample rank of query q (0: low side of bracket 0, 1: its high side, 2/3: bracket 1) -- fp64 square root and divisions,
     // so it is worked out only by the wave that scans for it, not by all sixteen.  A bracket rank beyond the sample is
-    // clamped to the sample's extreme: the bracket stays closed (an open side would gather the whole tail, ~1 % of the
-    // tile); the wanted element lying beyond all 4096 samples is a 1e-18 event and, like every bracket miss, is caught
-    // by the count check and repaired by the slow path.
+    // clamped to the sample's extreme here (the extreme still sets the bins); that side of the bracket is opened at the end.
     auto rank_of = [&](int q) -> uint32_t {
         long long lo_r, hi_r;
         if constexpr (kPoint) {      // precision="fast": the sample's own order statistic at the matching rank, no bracket
@@ -846,8 +848,24 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
     for (int s = 0; s < 2; ++s) {
         lo[s] = res[2 * s];
         hi[s] = res[2 * s + 1];
-        bin_origin[s] = bin_origin_for(lo[s]);      // candidate bins span the bracket
+        bin_origin[s] = bin_origin_for(lo[s]);      // candidate bins span the bracket (keys beyond an opened side land in the end bins)
         bin_scale[s] = bin_scale_for(lo[s], hi[s]);
+        if constexpr (!kPoint) {
+            // A bracket rank beyond the sample: that side is OPENED, not closed on the sample's extreme.  What lies beyond the
+            // extreme of m samples is 1/(m+1) of the selection set -- about one sample stride of keys, whatever m is --, while a
+            // bracket closed there misses whenever the wanted quantile is smaller than 1/(m+1): always for tiles with little
+            // tissue (a 48x48 patch on a 512x512 tile puts 36 selected pixels in the sample; its 1st percentile lies below all
+            // of them), and such a miss costs a whole-tile radix select (0.6 ms for one such tile in a config-2 batch).
+            // (A bracket whose two DIFFERENT sample ranks hold one key stays as it is: a tie group, resolved from its counts alone
+            // by the stages.  Two equal ranks -- a sample of one -- say nothing about ties.)
+            long long lo_r, hi_r;
+            bracket_ranks(m_valid, n_total, k0[s], lo_r, hi_r);
+            const long long lo_c = min(max(lo_r, 0ll), (long long)m_valid - 1), hi_c = min(max(hi_r, 0ll), (long long)m_valid - 1);
+            if (!(res[2 * s] == res[2 * s + 1] && hi_c > lo_c)) {
+                if (lo_r < 0) lo[s] = 0u;
+                if (hi_r > (long long)m_valid - 1) hi[s] = 0xFFFFFFFFu;
+            }
+        }
     }
 }
 
@@ -903,74 +921,88 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     // unbiased and averages out over the tile (~4e-9 on a covariance entry, measured against the fp64 covariance
     // in the tests), the cancellation in sum(xy) - sum(x)*mean(y) happens in fp64
     constexpr int kShortRun = 32 / V > 0 ? 32 / V : 1;      // packs per fp32 run
-    double acc[kPartial];
+    const int wave = threadIdx.x / kWave;
+    // kAll == false: the pixels the OD filter keeps (+ the sample on the way); kAll == true: every pixel
+    auto accumulate = [&](auto all_tag, double* __restrict__ dst) {
+        constexpr bool kAll = decltype(all_tag)::value;
+        double acc[kPartial];
 #pragma unroll
-    for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
-
-    for (int64_t run = p_begin; run < p_end; run += (int64_t)TPB * V * kShortRun) {
-        float m[kPartial];
+        for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
+        for (int64_t run = p_begin; run < p_end; run += (int64_t)TPB * V * kShortRun) {
+            float m[kPartial];
 #pragma unroll
-        for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
-        const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
-        for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
-            float u[3][V];
-            load_pixels<T, V, kInter>(img, g.pixels, p, u);
-            // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
-            // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
-            const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset(j, shift);
-            if (by_pack && (((gpos & mask) ^ off) >> kLog2V) == 0u && j < sample_count) {
-                float raw[3] = {u[0][0], u[1][0], u[2][0]};
+            for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
+            const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
+            for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
+                float u[3][V];
+                load_pixels<T, V, kInter>(img, g.pixels, p, u);
+                // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
+                // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
+                const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset(j, shift);
+                if (!kAll && by_pack && (((gpos & mask) ^ off) >> kLog2V) == 0u && j < sample_count) {
+                    float raw[3] = {u[0][0], u[1][0], u[2][0]};
 #pragma unroll
-                for (int i = 1; i < V; ++i)
-                    if ((int)(off & (uint32_t)(V - 1)) == i) {
+                    for (int i = 1; i < V; ++i)
+                        if ((int)(off & (uint32_t)(V - 1)) == i) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) raw[c] = u[c][i];
-                    }
+                            for (int c = 0; c < 3; ++c) raw[c] = u[c][i];
+                        }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], optical_density<T>(raw[c]));
-            }
-#pragma unroll
-            for (int i = 0; i < V; ++i) {
-                float od[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
-                if (!by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
-                    const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
-                    if ((pos & mask) == sample_offset(jj, shift) && jj < sample_count) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + jj], od[c]);
-                    }
+                    for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], optical_density<T>(raw[c]));
                 }
-                const float keep = od_selected(od, false) ? 1.0f : 0.0f;
-                const float k0 = keep * od[0], k1 = keep * od[1], k2 = keep * od[2];
-                m[0] += keep;
-                m[1] += k0;
-                m[2] += k1;
-                m[3] += k2;
-                m[4] = fmaf(k0, od[0], m[4]);
-                m[5] = fmaf(k0, od[1], m[5]);
-                m[6] = fmaf(k0, od[2], m[6]);
-                m[7] = fmaf(k1, od[1], m[7]);
-                m[8] = fmaf(k1, od[2], m[8]);
-                m[9] = fmaf(k2, od[2], m[9]);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    float od[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
+                    if (!kAll && !by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
+                        const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
+                        if ((pos & mask) == sample_offset(jj, shift) && jj < sample_count) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + jj], od[c]);
+                        }
+                    }
+                    const float keep = (kAll || od_selected(od, false)) ? 1.0f : 0.0f;
+                    const float k0 = keep * od[0], k1 = keep * od[1], k2 = keep * od[2];
+                    m[0] += keep;
+                    m[1] += k0;
+                    m[2] += k1;
+                    m[3] += k2;
+                    m[4] = fmaf(k0, od[0], m[4]);
+                    m[5] = fmaf(k0, od[1], m[5]);
+                    m[6] = fmaf(k0, od[2], m[6]);
+                    m[7] = fmaf(k1, od[1], m[7]);
+                    m[8] = fmaf(k1, od[2], m[8]);
+                    m[9] = fmaf(k2, od[2], m[9]);
+                }
             }
+#pragma unroll
+            for (int k = 0; k < kPartial; ++k) acc[k] += (double)m[k];
         }
 #pragma unroll
-        for (int k = 0; k < kPartial; ++k) acc[k] += (double)m[k];
-    }
-
-    const int wave = threadIdx.x / kWave;
+        for (int k = 0; k < kPartial; ++k) {
+            const double s = wave_total_f64(acc[k]);       // fixed order; lane 63 holds the total
+            if (lane_id() == kWave - 1) sh->red[wave][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < kPartial) {
+            double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < kPartial; ++k) {
-        const double s = wave_total_f64(acc[k]);       // fixed order; lane 63 holds the total
-        if (lane_id() == kWave - 1) sh->red[wave][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kPartial) {
-        double s = 0.0;
+            for (int w = 0; w < TPB / kWave; ++w) s += sh->red[w][threadIdx.x];
+            put(&dst[item * kPartial + threadIdx.x], s);
+        }
+    };
+    accumulate(std::false_type{}, ws.partial);
+    // A work item none of whose pixels pass the OD filter also leaves the moments of ALL its pixels: a tile with fewer than 3
+    // kept pixels takes every pixel (torch_backend.py:409-410), and then each of its work items is such a one -- the plane
+    // stage adds the partial sums up instead of streaming the whole tile through one workgroup (0.1 ms per blank tile).
+    // Work items of ordinary tiles never get here; the second sweep reads what the first just brought in.
+    double kept = 0.0;
 #pragma unroll
-        for (int w = 0; w < TPB / kWave; ++w) s += sh->red[w][threadIdx.x];
-        put(&ws.partial[item * kPartial + threadIdx.x], s);
+    for (int w = 0; w < TPB / kWave; ++w) kept += sh->red[w][0];      // workgroup-uniform
+    if (__builtin_expect(kept < 3.0, 0)) {
+        __syncthreads();      // everyone has read the kept count
+        accumulate(std::true_type{}, ws.partial_all);
     }
 }
 
@@ -1239,36 +1271,22 @@ __device__ __forceinline__ void load_sample(const Workspace& ws, int group, int 
     }
 }
 
-// Raw moments of ALL pixels of a group (torch_backend.py:409-410: fewer than 3 pixels pass the OD filter), by the
-// one workgroup of the per-tile stage: per-thread fp64 sums, fixed-order reduction.  Slow path.
-template <typename T>
-__device__ void all_pixel_moments(const T* __restrict__ images, const Geometry& g, int group, TileScratch* sh) {
-    const GroupPixels gp = group_pixels(g, group);
-    double acc[kPartial];
-#pragma unroll
-    for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
-    for (int64_t i = threadIdx.x; i < gp.count; i += blockDim.x) {
-        int64_t tile, p;
-        gp.locate(i, tile, p);
-        float od[3];
-        load_od_scalar<T>(images, g, tile, p, od);
-        const double x = od[0], y = od[1], z = od[2];
-        acc[0] += 1.0; acc[1] += x; acc[2] += y; acc[3] += z;
-        acc[4] += x * x; acc[5] += x * y; acc[6] += x * z; acc[7] += y * y; acc[8] += y * z; acc[9] += z * z;
+// Raw moments of ALL pixels of a tile (torch_backend.py:409-410: fewer than 3 pixels pass the OD filter): every work
+// item of such a tile has left them in ws.partial_all (stats_item); added up in index order like the kept set.
+__device__ void all_pixel_moments(const Geometry& g, const Workspace& ws, int group, TileScratch* sh) {
+    const int64_t first = (int64_t)group * g.blocks_per_tile;
+    const int64_t nblk = g.blocks_per_tile;
+    const int rows = 64;
+    double running = 0.0;
+    for (int64_t b0 = 0; b0 < nblk; b0 += rows) {
+        const int live = (int)min((int64_t)rows, nblk - b0);
+        __syncthreads();
+        if ((int)threadIdx.x < live * kPartial) sh->stage[threadIdx.x / kPartial][threadIdx.x % kPartial] = get(&ws.partial_all[(first + b0) * kPartial + threadIdx.x]);
+        __syncthreads();
+        if (threadIdx.x < kPartial)
+            for (int b = 0; b < live; ++b) running += sh->stage[b][threadIdx.x];
     }
-    const int wave = threadIdx.x / kWave, n_waves = blockDim.x / kWave;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kPartial; ++k) {
-        const double s = wave_total_f64(acc[k]);
-        if (lane_id() == kWave - 1) sh->stage[wave][k] = s;      // n_waves <= 64 rows
-    }
-    __syncthreads();
-    if (threadIdx.x < kPartial) {
-        double s = 0.0;
-        for (int w = 0; w < n_waves; ++w) s += sh->stage[w][threadIdx.x];
-        sh->mom[kPartial + threadIdx.x] = s;
-    }
+    if (threadIdx.x < kPartial) sh->mom[kPartial + threadIdx.x] = running;
     __syncthreads();
 }
 
@@ -1306,7 +1324,7 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
         if (threadIdx.x > kPartial && threadIdx.x < kMoments) sh->mom[threadIdx.x] = 0.0;   // the sums only matter in the fallback below
     }
     __syncthreads();
-    if (__builtin_expect(allow_fallback && sh->mom[0] < 3.0, 0)) all_pixel_moments<T>(images, g, group, sh);     // uniform, rare (blank tiles)
+    if (__builtin_expect(allow_fallback && !g.pooled && sh->mom[0] < 3.0, 0)) all_pixel_moments(g, ws, group, sh);     // uniform, rare (blank tiles)
     __syncthreads();
     SX_STAMP(st, 1);
     if (threadIdx.x == 0) {
