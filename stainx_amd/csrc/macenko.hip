@@ -659,6 +659,7 @@ struct alignas(16) TileScratch {
     double stage[64][kPartial];
     unsigned long long radix_rank, n_sel;
     uint32_t bin_s[4], rank_in_bin_s[4], count_s[4], result_s[4];
+    uint32_t rank_s[4], beyond_s[4];      // sample rank of each bracket side (clamped into the sample) and whether it lay beyond the sample
     uint32_t range_c[2][2], rank_in_bin_c[2], count_c[2], result_c[2];
     uint32_t range_lo[2], range_hi[2], radix_digit;
     uint32_t valid;
@@ -774,7 +775,7 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
     // Sample rank of query q (0: low side of bracket 0, 1: its high side, 2/3: bracket 1) -- fp64 square root and divisions,
     // so it is worked out only by the wave that scans for it, not by all sixteen.  A bracket rank beyond the sample is
     // clamped to the sample's extreme here (the extreme still sets the bins); that side of the bracket is opened at the end.
-    auto rank_of = [&](int q) -> uint32_t {
+    auto rank_of = [&](int q, bool& beyond) -> uint32_t {
         long long lo_r, hi_r;
         if constexpr (kPoint) {      // precision="fast": the sample's own order statistic at the matching rank, no bracket
             const unsigned long long k = (q >> 1) ? k0[1] : k0[0];
@@ -783,7 +784,9 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
         } else {
             bracket_ranks(m_valid, n_total, (q >> 1) ? k0[1] : k0[0], lo_r, hi_r);
         }
-        return (uint32_t)min(max((q & 1) ? hi_r : lo_r, 0ll), (long long)m_valid - 1);
+        const long long want = (q & 1) ? hi_r : lo_r;
+        beyond = want < 0 || want > (long long)m_valid - 1;
+        return (uint32_t)min(max(want, 0ll), (long long)m_valid - 1);
     };
     uint32_t bin[kSets][kKeys];
 #pragma unroll
@@ -801,10 +804,14 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
     const int wave = threadIdx.x / kWave;
     if (wave < 4) {
         uint32_t b, rb;
-        scan_pick32(sh->hist_s[kSets == 2 ? (wave >> 1) : 0], rank_of(wave), b, rb);
+        bool beyond;
+        const uint32_t r = rank_of(wave, beyond);
+        scan_pick32(sh->hist_s[kSets == 2 ? (wave >> 1) : 0], r, b, rb);
         if (lane == 0) {
             sh->bin_s[wave] = b;
             sh->rank_in_bin_s[wave] = rb;
+            sh->rank_s[wave] = r;
+            sh->beyond_s[wave] = beyond ? 1u : 0u;
         }
     }
     __syncthreads();
@@ -841,7 +848,8 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t* keys = sh->keys[kSets == 2 ? (q >> 1) : 0];
-            res[q] = radix_select_stream((unsigned long long)kSample, (unsigned long long)rank_of(q), [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return k != 0xFFFFFFFFu; }, sh);
+            bool unused;
+            res[q] = radix_select_stream((unsigned long long)kSample, (unsigned long long)rank_of(q, unused), [keys](unsigned long long i, uint32_t& k) { k = keys[i]; return k != 0xFFFFFFFFu; }, sh);
         }
     }
 #pragma unroll
@@ -858,12 +866,10 @@ __device__ void sample_brackets(TileScratch* sh, const uint32_t (&key)[kSets][kK
             // of them), and such a miss costs a whole-tile radix select (0.6 ms for one such tile in a config-2 batch).
             // (A bracket whose two DIFFERENT sample ranks hold one key stays as it is: a tie group, resolved from its counts alone
             // by the stages.  Two equal ranks -- a sample of one -- say nothing about ties.)
-            long long lo_r, hi_r;
-            bracket_ranks(m_valid, n_total, k0[s], lo_r, hi_r);
-            const long long lo_c = min(max(lo_r, 0ll), (long long)m_valid - 1), hi_c = min(max(hi_r, 0ll), (long long)m_valid - 1);
-            if (!(res[2 * s] == res[2 * s + 1] && hi_c > lo_c)) {
-                if (lo_r < 0) lo[s] = 0u;
-                if (hi_r > (long long)m_valid - 1) hi[s] = 0xFFFFFFFFu;
+            // (the ranks were worked out by the scanning waves; here they are two LDS words per side)
+            if (!(res[2 * s] == res[2 * s + 1] && sh->rank_s[2 * s + 1] > sh->rank_s[2 * s])) {
+                if (sh->beyond_s[2 * s]) lo[s] = 0u;
+                if (sh->beyond_s[2 * s + 1]) hi[s] = 0xFFFFFFFFu;
             }
         }
     }
@@ -903,6 +909,58 @@ template <int TPB> struct StatsScratch {
     double red[TPB / kWave][kPartial];
 };
 
+// Moments of ALL pixels of a work item (see the end of stats_item): the same fp32 runs / fp64 sums as the kept set.  Not
+// (ordinary tiles never run it).
+template <typename T, int V, int TPB, bool kInter>
+__device__ __forceinline__ void stats_item_all_pixels(const T* __restrict__ img, int64_t pixels, int64_t p_begin, int64_t p_end, double* __restrict__ dst, StatsScratch<TPB>* sh) {
+    constexpr int kShortRun = 32 / V > 0 ? 32 / V : 1;
+    double acc[kPartial];
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
+    for (int64_t run = p_begin; run < p_end; run += (int64_t)TPB * V * kShortRun) {
+        float m[kPartial];
+#pragma unroll
+        for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
+        const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
+        for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
+            float u[3][V];
+            load_pixels<T, V, kInter>(img, pixels, p, u);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float od[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
+                m[0] += 1.0f;
+                m[1] += od[0];
+                m[2] += od[1];
+                m[3] += od[2];
+                m[4] = fmaf(od[0], od[0], m[4]);
+                m[5] = fmaf(od[0], od[1], m[5]);
+                m[6] = fmaf(od[0], od[2], m[6]);
+                m[7] = fmaf(od[1], od[1], m[7]);
+                m[8] = fmaf(od[1], od[2], m[8]);
+                m[9] = fmaf(od[2], od[2], m[9]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPartial; ++k) acc[k] += (double)m[k];
+    }
+    const int wave = threadIdx.x / kWave;
+    __syncthreads();      // everyone is done with the kept set's sums in the scratch
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) {
+        const double s = wave_total_f64(acc[k]);
+        if (lane_id() == kWave - 1) sh->red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartial) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < TPB / kWave; ++w) s += sh->red[w][threadIdx.x];
+        put(&dst[threadIdx.x], s);
+    }
+}
+
 template <typename T, int V, int TPB, bool kInter>
 __device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh) {
     const int64_t p_begin = (int64_t)chunk_id * g.chunk;
@@ -921,78 +979,75 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     // unbiased and averages out over the tile (~4e-9 on a covariance entry, measured against the fp64 covariance
     // in the tests), the cancellation in sum(xy) - sum(x)*mean(y) happens in fp64
     constexpr int kShortRun = 32 / V > 0 ? 32 / V : 1;      // packs per fp32 run
-    const int wave = threadIdx.x / kWave;
-    // kAll == false: the pixels the OD filter keeps (+ the sample on the way); kAll == true: every pixel
-    auto accumulate = [&](auto all_tag, double* __restrict__ dst) {
-        constexpr bool kAll = decltype(all_tag)::value;
-        double acc[kPartial];
+    double acc[kPartial];
 #pragma unroll
-        for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
-        for (int64_t run = p_begin; run < p_end; run += (int64_t)TPB * V * kShortRun) {
-            float m[kPartial];
+    for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
+
+    for (int64_t run = p_begin; run < p_end; run += (int64_t)TPB * V * kShortRun) {
+        float m[kPartial];
 #pragma unroll
-            for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
-            const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
-            for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
-                float u[3][V];
-                load_pixels<T, V, kInter>(img, g.pixels, p, u);
-                // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
-                // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
-                const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset(j, shift);
-                if (!kAll && by_pack && (((gpos & mask) ^ off) >> kLog2V) == 0u && j < sample_count) {
-                    float raw[3] = {u[0][0], u[1][0], u[2][0]};
+        for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
+        const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
+        for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
+            float u[3][V];
+            load_pixels<T, V, kInter>(img, g.pixels, p, u);
+            // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
+            // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
+            const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset(j, shift);
+            if (by_pack && (((gpos & mask) ^ off) >> kLog2V) == 0u && j < sample_count) {
+                float raw[3] = {u[0][0], u[1][0], u[2][0]};
 #pragma unroll
-                    for (int i = 1; i < V; ++i)
-                        if ((int)(off & (uint32_t)(V - 1)) == i) {
+                for (int i = 1; i < V; ++i)
+                    if ((int)(off & (uint32_t)(V - 1)) == i) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) raw[c] = u[c][i];
-                        }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], optical_density<T>(raw[c]));
-                }
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    float od[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
-                    if (!kAll && !by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
-                        const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
-                        if ((pos & mask) == sample_offset(jj, shift) && jj < sample_count) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + jj], od[c]);
-                        }
+                        for (int c = 0; c < 3; ++c) raw[c] = u[c][i];
                     }
-                    const float keep = (kAll || od_selected(od, false)) ? 1.0f : 0.0f;
-                    const float k0 = keep * od[0], k1 = keep * od[1], k2 = keep * od[2];
-                    m[0] += keep;
-                    m[1] += k0;
-                    m[2] += k1;
-                    m[3] += k2;
-                    m[4] = fmaf(k0, od[0], m[4]);
-                    m[5] = fmaf(k0, od[1], m[5]);
-                    m[6] = fmaf(k0, od[2], m[6]);
-                    m[7] = fmaf(k1, od[1], m[7]);
-                    m[8] = fmaf(k1, od[2], m[8]);
-                    m[9] = fmaf(k2, od[2], m[9]);
-                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], optical_density<T>(raw[c]));
             }
 #pragma unroll
-            for (int k = 0; k < kPartial; ++k) acc[k] += (double)m[k];
+            for (int i = 0; i < V; ++i) {
+                float od[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
+                if (!by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
+                    const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
+                    if ((pos & mask) == sample_offset(jj, shift) && jj < sample_count) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + jj], od[c]);
+                    }
+                }
+                const float keep = od_selected(od, false) ? 1.0f : 0.0f;
+                const float k0 = keep * od[0], k1 = keep * od[1], k2 = keep * od[2];
+                m[0] += keep;
+                m[1] += k0;
+                m[2] += k1;
+                m[3] += k2;
+                m[4] = fmaf(k0, od[0], m[4]);
+                m[5] = fmaf(k0, od[1], m[5]);
+                m[6] = fmaf(k0, od[2], m[6]);
+                m[7] = fmaf(k1, od[1], m[7]);
+                m[8] = fmaf(k1, od[2], m[8]);
+                m[9] = fmaf(k2, od[2], m[9]);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < kPartial; ++k) {
-            const double s = wave_total_f64(acc[k]);       // fixed order; lane 63 holds the total
-            if (lane_id() == kWave - 1) sh->red[wave][k] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < kPartial) {
-            double s = 0.0;
+        for (int k = 0; k < kPartial; ++k) acc[k] += (double)m[k];
+    }
+
+    const int wave = threadIdx.x / kWave;
 #pragma unroll
-            for (int w = 0; w < TPB / kWave; ++w) s += sh->red[w][threadIdx.x];
-            put(&dst[item * kPartial + threadIdx.x], s);
-        }
-    };
-    accumulate(std::false_type{}, ws.partial);
+    for (int k = 0; k < kPartial; ++k) {
+        const double s = wave_total_f64(acc[k]);       // fixed order; lane 63 holds the total
+        if (lane_id() == kWave - 1) sh->red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartial) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < TPB / kWave; ++w) s += sh->red[w][threadIdx.x];
+        put(&ws.partial[item * kPartial + threadIdx.x], s);
+    }
     // A work item none of whose pixels pass the OD filter also leaves the moments of ALL its pixels: a tile with fewer than 3
     // kept pixels takes every pixel (torch_backend.py:409-410), and then each of its work items is such a one -- the plane
     // stage adds the partial sums up instead of streaming the whole tile through one workgroup (0.1 ms per blank tile).
@@ -1000,10 +1055,7 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     double kept = 0.0;
 #pragma unroll
     for (int w = 0; w < TPB / kWave; ++w) kept += sh->red[w][0];      // workgroup-uniform
-    if (__builtin_expect(kept < 3.0, 0)) {
-        __syncthreads();      // everyone has read the kept count
-        accumulate(std::true_type{}, ws.partial_all);
-    }
+    if (__builtin_expect(kept < 3.0, 0)) stats_item_all_pixels<T, V, TPB, kInter>(img, g.pixels, p_begin, p_end, ws.partial_all + item * kPartial, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
