@@ -62,3 +62,28 @@ for ti in range(6):
             cand = (cmax >= Qlo) & (cmin <= Qhi)
             fr.append(cand.mean())
         print(f"tile {ti} sample {m:5d}: dphi_a {a_hi-a_lo:.4f} dphi_b {b_hi-b_lo:.4f} gap {pb-pa:.3f}  C-candidate fraction {fr[0]*100:.1f}% / {fr[1]*100:.1f}%   (phi candidates {(np.mean((theta>=a_lo)&(theta<=a_hi))+np.mean((theta>=b_lo)&(theta<=b_hi)))*100:.1f}%)")
+        # ---- the simpler form: speculate at the sample's own percentiles, bound the deviation ----
+        # C = A(phi_a, phi_b) t is linear in t; with A_hat at the sample percentiles |C - C_hat| <= B (|t0| + |t1|), B = max over
+        # the bracket corners of ||A - A_hat||_inf (checked in fp64 once phi is exact).  A pixel is stored unless
+        # C_hat + B s < lo_w (definitely below) or C_hat - B s > hi_w (definitely above); lo_w / hi_w are the bracket-rank order
+        # statistics of the sample's own lower / upper bounds (order statistics are monotone: rigorous).
+        def A_of(pa_, pb_):
+            det = np.sin(pb_ - pa_)
+            return np.array([[np.sin(pb_), -np.cos(pb_)], [-np.sin(pa_), np.cos(pa_)]]) / det
+        pa_hat, pb_hat = th_s[nearest_rank(mv, 1.0)], th_s[nearest_rank(mv, 99.0)]
+        A_hat = A_of(pa_hat, pb_hat)
+        s_all = np.abs(t[:, 0]) + np.abs(t[:, 1])
+        band = []
+        for k in (0, 1):
+            B = max(np.abs(A_of(x_, y_)[k] - A_hat[k]).max() for x_ in (a_lo, a_hi) for y_ in (b_lo, b_hi))
+            assert np.abs(A_of(pa, pb)[k] - A_hat[k]).max() <= B
+            c_hat = t @ A_hat[k]
+            lo_r, hi_r = bracket_ranks(m, P, nearest_rank(P, 99.0))
+            lo_w = np.sort((c_hat - B * s_all)[idx])[lo_r]
+            hi_w = np.sort((c_hat + B * s_all)[idx])[hi_r]
+            stored = (c_hat + B * s_all >= lo_w) & (c_hat - B * s_all <= hi_w)
+            c_exact = t @ A_of(pa, pb)[k]
+            cs = np.sort(c_exact)
+            assert lo_w <= cs[nearest_rank(P, 99.0)] <= hi_w
+            band.append(stored.mean())
+        print(f"          verified-bound form: stored {band[0]*100:.1f}% / {band[1]*100:.1f}% of the pixels")
