@@ -615,8 +615,11 @@ __device__ __forceinline__ void rank_pick(const uint32_t* list, uint32_t n, uint
 // crowd: float keys spend one binade per exponent) and monotone in the key.  Values beyond the range
 // (open brackets) go to the end bins; a degenerate range gets scale 0 (everything in bin 0 -> radix paths).
 __device__ __forceinline__ uint32_t bin_of(uint32_t key, double origin, double scale) {
-    const double d = ((double)key_float(key) - origin) * scale;
-    return (uint32_t)fmin(fmax(d, 0.0), 255.0);
+    // fp32: a subtraction of a constant and a multiplication by a non-negative constant are monotone under rounding, which is
+    // all a bin function needs (the same function everywhere, non-decreasing in the key); the origin is a float to begin
+    // with.  The fp64 form (seven half-rate instructions per key) made the candidate filter the longest phase of the stages.
+    const float d = (key_float(key) - (float)origin) * (float)scale;
+    return (uint32_t)fminf(fmaxf(d, 0.0f), 255.0f);
 }
 __device__ __forceinline__ double bin_origin_for(uint32_t lo) { return (double)key_float(lo); }
 __device__ __forceinline__ double bin_scale_for(uint32_t lo, uint32_t hi) {
