@@ -358,6 +358,9 @@ __device__ void jacobi_eigh3(const double a_in[9], double w[3], double q[9]) {
 // product.  ~250 dependent fp64 operations instead of ~1000 (3 us -> 0.8 us on the one lane that runs this).  The result
 // is accepted only if both residuals |A v - (v'Av) v| are at rounding level; otherwise -- close eigenvalues, degenerate
 // covariance -- the caller runs the Jacobi iteration.  Columns of q as jacobi_eigh3 returns them (ascending eigenvalue).
+// kPair: lanes 0 and 1 of a wave call this together with the same matrix; the two power iterations (the same code on different
+// data) run side by side, one per lane, and are exchanged; both lanes return the same result.
+template <bool kPair = false>
 __device__ inline bool plane_basis_by_squaring(const double a[9], double q[9]) {
     const double trace = a[0] + a[4] + a[8];
     if (!(trace > 0.0)) return false;
@@ -386,9 +389,27 @@ __device__ inline bool plane_basis_by_squaring(const double a[9], double q[9]) {
     const double s = 1.0 / trace;      // scale the matrix to trace 1
     const double a00 = a[0] * s, a01 = a[1] * s, a02 = a[2] * s, a11 = a[4] * s, a12 = a[5] * s, a22 = a[8] * s;
     double v_max[3], v_min[3];
-    if (!dominant(a00, a01, a02, a11, a12, a22, v_max)) return false;
-    // adjugate (cofactors) of the scaled matrix
-    if (!dominant(a11 * a22 - a12 * a12, a02 * a12 - a01 * a22, a01 * a12 - a02 * a11, a00 * a22 - a02 * a02, a01 * a02 - a00 * a12, a00 * a11 - a01 * a01, v_min)) return false;
+    // the smallest eigenvector is the dominant one of the adjugate (cofactors) of the scaled matrix
+    const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11, c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12,
+                 c22 = a00 * a11 - a01 * a01;
+    if constexpr (kPair) {
+        const bool second = (lane_id() & 1u) != 0;
+        double mine[3], other[3];
+        const bool ok_mine = dominant(second ? c00 : a00, second ? c01 : a01, second ? c02 : a02, second ? c11 : a11, second ? c12 : a12, second ? c22 : a22, mine);
+        const int partner = (int)(lane_id() ^ 1u);
+        const bool ok_other = __shfl(ok_mine ? 1 : 0, partner, kWave) != 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) other[i] = __shfl(ok_mine ? mine[i] : 0.0, partner, kWave);
+        if (!(ok_mine && ok_other)) return false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            v_max[i] = second ? other[i] : mine[i];
+            v_min[i] = second ? mine[i] : other[i];
+        }
+    } else {
+        if (!dominant(a00, a01, a02, a11, a12, a22, v_max)) return false;
+        if (!dominant(c00, c01, c02, c11, c12, c22, v_min)) return false;
+    }
     // the middle eigenvector: orthogonal to both; then v_max once more against (v_min, v_mid) so that the three are
     // orthonormal to rounding
     double mx = v_min[1] * v_max[2] - v_min[2] * v_max[1], my = v_min[2] * v_max[0] - v_min[0] * v_max[2], mz = v_min[0] * v_max[1] - v_min[1] * v_max[0];
@@ -415,6 +436,7 @@ __device__ inline bool plane_basis_by_squaring(const double a[9], double q[9]) {
 // Raw moments -> unbiased covariance (torch_backend.py:395-397) -> plane vectors, columns [1,2] of eigh
 // (torch_backend.py:415), sign convention: positive component sum.  mom[0..9] masked set, mom[10..19] all pixels;
 // fewer than 3 masked pixels -> all pixels when allow_fallback (torch_backend.py:409-410).
+template <bool kPair = false>
 __device__ void plane_from_moments(const double* mom, bool allow_fallback, double cov[9], float vecs[6], bool& use_all, unsigned long long& n_sel) {
     use_all = allow_fallback && mom[0] < 3.0;
     const double* a = use_all ? mom + 10 : mom;
@@ -433,7 +455,7 @@ __device__ void plane_from_moments(const double* mom, bool allow_fallback, doubl
         for (int i = 0; i < 9; ++i) cov[i] = 0.0;
     }
     double w[3], q[9];
-    if (!plane_basis_by_squaring(cov, q)) jacobi_eigh3(cov, w, q);
+    if (!plane_basis_by_squaring<kPair>(cov, q)) jacobi_eigh3(cov, w, q);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int src = c + 1;
@@ -1382,12 +1404,13 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
     if (__builtin_expect(allow_fallback && !g.pooled && sh->mom[0] < 3.0, 0)) all_pixel_moments(g, ws, group, sh);     // uniform, rare (blank tiles)
     __syncthreads();
     SX_STAMP(st, 1);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 2) {      // two lanes: the eigen step's two power iterations side by side (lane 1 only helps)
         double cov[9];
         bool use_all;
         unsigned long long n_sel;
         float vecs[6];
-        plane_from_moments(sh->mom, allow_fallback != 0, cov, vecs, use_all, n_sel);
+        plane_from_moments<true>(sh->mom, allow_fallback != 0, cov, vecs, use_all, n_sel);
+      if (threadIdx.x == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             sh->coef[i] = vecs[i];
@@ -1407,6 +1430,7 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
             put(&st.below[s], 0u);
             put(&st.ncand[s], 0u);
         }
+      }
     }
     if (g.fine_chunk) {      // the tile's histogram is added to by many small work items: start from zero
         uint32_t* row = ws.block_hist + (size_t)group * g.blocks_per_tile * 512;
