@@ -44,6 +44,10 @@ typedef enum {
 #define SX_MACENKO_NORMALIZE_0_1 1u /* fuse `result / 255.0` (normalizers/_template.py:111-112); u8 input -> f32 output */
 #define SX_MACENKO_FAST 4u          /* Macenko(precision="fast") (normalizers/macenko.py:35-44, a relaxed-accuracy path in the reference too): the
                                       percentiles of a 4096-pixel sample of each tile stand in for the exact ones -- two passes instead of four */
+#define SX_MACENKO_OUT_BF16 32u      /* uint8 input only: the result is written as bfloat16 -- bit for bit `transform(x).to(bfloat16)`, with
+                                       SX_MACENKO_NORMALIZE_0_1 `transform(x, normalize_to_0_1).to(bfloat16)` -- so a uint8 tile from the decoder
+                                       becomes a model's bf16 input with 3 bytes read and 6 written per pixel (an extension: SURVEY.md 8f-2) */
+#define SX_MACENKO_OUT_F16 64u       /* the same with float16 */
 #define SX_MACENKO_NO_TIE_SHORTCUT 8u /* diagnostic: do not resolve a bracket that closed on one key from its counts (forces the slow exact paths; tests) */
 #define SX_MACENKO_CHANNELS_LAST 2u /* images and output are (N,H,W,3) (decoder / PIL layout) instead of (N,3,H,W); an extension: the
                                       reference takes NCHW only and callers permute + copy first */

@@ -68,10 +68,18 @@ class MacenkoHIP(TorchHIPBackendBase):
             raise ValueError(f"Macenko {what} expects 3 channels in dim 1 (NCHW), got C={images.shape[1]} with shape {tuple(images.shape)}")
 
     def transform(self, images: torch.Tensor, stain_matrix: torch.Tensor, target_max_conc: torch.Tensor, *, normalize_to_0_1: bool = False,
-                  channels_last: bool = False, _extra_flags: int = 0) -> torch.Tensor:
+                  channels_last: bool = False, out_dtype: torch.dtype | None = None, _extra_flags: int = 0) -> torch.Tensor:
         """``channels_last=True`` (an extension; the reference takes NCHW only): ``images`` is (N,H,W,3) as decoders and PIL
-        hand tiles over, and so is the result -- the permute + copy a caller would otherwise do first is fused away."""
+        hand tiles over, and so is the result -- the permute + copy a caller would otherwise do first is fused away.
+        ``out_dtype=torch.bfloat16 / torch.float16`` (an extension, uint8 input only): the result of the call without it, cast
+        with ``.to(out_dtype)``, written directly -- a decoder's uint8 tile becomes a model's half-precision input in one call."""
         images = images.to(self.device)
+        if out_dtype is not None and out_dtype != images.dtype:
+            if images.dtype != torch.uint8 or out_dtype not in (torch.bfloat16, torch.float16):
+                raise ValueError(f"out_dtype is supported for uint8 input and bfloat16 / float16 output, got {images.dtype} -> {out_dtype}")
+            _extra_flags = int(_extra_flags) | (_native.MACENKO_OUT_BF16 if out_dtype == torch.bfloat16 else _native.MACENKO_OUT_F16)
+        else:
+            out_dtype = None
         if tuple(stain_matrix.shape) != (3, 2):
             raise ValueError(f"stain_matrix must have shape (3, 2), got {stain_matrix.shape}")
         if channels_last:
@@ -86,7 +94,8 @@ class MacenkoHIP(TorchHIPBackendBase):
         images = images.contiguous()
         n, h, w = (images.shape[0], images.shape[1], images.shape[2]) if channels_last else (images.shape[0], images.shape[2], images.shape[3])
         code = _dtype_code(images)
-        out_dtype = torch.float32 if (normalize_to_0_1 and images.dtype == torch.uint8) else images.dtype
+        if out_dtype is None:
+            out_dtype = torch.float32 if (normalize_to_0_1 and images.dtype == torch.uint8) else images.dtype
         out = torch.empty(tuple(images.shape), dtype=out_dtype, device=self.device)
         if n == 0 or h * w == 0:
             return out

@@ -95,6 +95,7 @@ struct Geometry {
     int chunk;                    // pixels per work item: the tile split evenly over its blocks_per_tile work items (<= kChunk)
     int vec_width;                // pixels per 16-byte pack of the element type (host side, for the chunk rounding)
     int no_tie;                   // diagnostic (SX_MACENKO_NO_TIE_SHORTCUT): never resolve a closed bracket from its counts alone
+    int out_code;                 // uint8 input only: SX_BF16 / SX_F16 output (SX_MACENKO_OUT_*), 0 = the reference's output type
 };
 
 // Pooled fit over several tiles ("spread" mode): the streaming stages keep candidates, counters and histograms per
@@ -272,6 +273,37 @@ __device__ __forceinline__ void store_pixels(O* __restrict__ dst, int64_t pixels
 #pragma unroll
         for (int c = 0; c < 3; ++c) store_pack_stream<O, V>(dst + c * pixels + p, res[c]);
     }
+}
+
+// Interleaved tiles, 16-byte packs: a lane's three packs are 48 consecutive bytes of the output, so a plain store instruction
+// of the wave touches 64 different 48-byte pieces.  Staged through 3 KB of LDS per wave, every store instruction writes 1 KB of
+// consecutive bytes instead (lane L, instruction s: bytes [1024 s + 16 L, +16) of the wave's 3 KB).  All 64 lanes take part.
+template <typename O, int V>
+__device__ __forceinline__ void store_pixels_staged(O* __restrict__ dst, int64_t p, const O (&res)[3][V], uint4* __restrict__ stage) {
+    static_assert(sizeof(O) * V == 16, "16-byte packs");
+    O flat[3][V];
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) flat[(3 * i + c) / V][(3 * i + c) % V] = res[c][i];
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint4 v;
+        __builtin_memcpy(&v, flat[k], 16);
+        stage[lane * 3 + k] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    char* base = reinterpret_cast<char*>(dst + 3 * (p - (int64_t)lane * V));      // the wave's first byte
+    typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+        const uint4 v = stage[s2 * kWave + lane];
+        f4 f;
+        __builtin_memcpy(&f, &v, 16);
+        __builtin_nontemporal_store(f, reinterpret_cast<f4*>(base + ((size_t)s2 * kWave + lane) * 16));
+    }
+    __builtin_amdgcn_wave_barrier();      // the next iteration overwrites the stage
 }
 
 template <typename T>
@@ -1266,7 +1298,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename O, int V, bool kUnit, int TPB, bool kInter>
 __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
-                                 const float* __restrict__ stain_matrix) {
+                                 const float* __restrict__ stain_matrix, uint4* __restrict__ stage = nullptr) {
     const int64_t chunk = g.fine_chunk ? g.fine_chunk : g.chunk;
     const int64_t p_begin = (int64_t)chunk_id * chunk;
     const int64_t p_end = min(p_begin + chunk, g.pixels);
@@ -1317,17 +1349,25 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
                 rgb = fminf(fmaxf(rgb, 0.0f), 255.0f);                                // :459, :128
                 if constexpr (kUnit) {
                     // cast to the input dtype first, then /255 in that dtype (_template.py:111-112);
-                    // u8 promotes to f32
+                    // u8 promotes to f32 (and, with SX_MACENKO_OUT_*, that f32 is cast once more: `.to(bfloat16)` fused)
                     if constexpr (sizeof(T) == 1) {
-                        res[c][i] = (float)Elem<T>::store(rgb) / 255.0f;
+                        res[c][i] = Elem<O>::store((float)Elem<T>::store(rgb) / 255.0f);
                     } else if constexpr (sizeof(T) == 8) {
                         res[c][i] = (double)rgb / 255.0;
                     } else {
                         res[c][i] = Elem<O>::store(Elem<T>::load(Elem<T>::store(rgb)) / 255.0f);
                     }
+                } else if constexpr (sizeof(T) == 1 && sizeof(O) == 2) {
+                    res[c][i] = Elem<O>::store((float)Elem<T>::store(rgb));      // the truncated grey level, exactly representable
                 } else {
                     res[c][i] = Elem<O>::store(rgb);
                 }
+            }
+        }
+        if constexpr (kInter && V > 1 && sizeof(O) * V == 16) {
+            if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {      // wave-uniform: every lane has a pack (all but a tile's last sweep)
+                store_pixels_staged<O, V>(dst, p, res, stage + (threadIdx.x / kWave) * (3 * kWave));
+                continue;
             }
         }
         store_pixels<O, V, kInter>(dst, g.pixels, p, res);
@@ -2005,7 +2045,12 @@ __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __rest
 template <typename T, typename O, int V, bool kUnit, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __restrict__ images, O* __restrict__ out, Geometry g, Workspace ws, const float* __restrict__ stain_matrix) {
     const int per_tile = g.fine_chunk ? g.fine_blocks : g.blocks_per_tile;
-    reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix);
+    if constexpr (kInter && V > 1) {
+        __shared__ uint4 stage[kStreamThreads * 3];      // 3 KB per wave: store_pixels_staged()
+        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix, stage);
+    } else {
+        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix);
+    }
 }
 
 
@@ -2252,18 +2297,24 @@ static int run_transform(const T* images, O* out, const Geometry& g, const Works
         rc = run_estimate<T, V, kInter>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
     }
     if (rc != SX_OK) return rc;
+    // The reconstruct pass is paced by its stores: its pack is 16 bytes of OUTPUT per lane and plane, so that one store
+    // instruction of a wave writes 1 KB of consecutive bytes.  With the input's pack (16 pixels per lane for uint8) a wider output
+    // type leaves every lane 64-192 bytes of its own and every store instruction 64 different lines: uint8 -> float32 (/255)
+    // took 172 us planar and 569 us NHWC for the config-2 batch where the same-width uint8 output takes 24 us.
+    constexpr int VR = V == 1 ? 1 : ((int)(16 / sizeof(O)) < V ? (int)(16 / sizeof(O)) : V);
     if (unit)
-        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, true, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
+        hipLaunchKernelGGL((reconstruct_kernel<T, O, VR, true, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
     else
-        hipLaunchKernelGGL((reconstruct_kernel<T, O, V, false, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
+        hipLaunchKernelGGL((reconstruct_kernel<T, O, VR, false, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
     return check_launch("macenko reconstruct");
 }
 
 template <typename T>
 static int transform_typed(const void* images, void* out, const Geometry& g0, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
     Geometry g = g0;
-    const bool u8_unit = unit && sizeof(T) == 1;
-    const size_t out_elem = u8_unit ? sizeof(float) : sizeof(T);
+    const bool u8_half = sizeof(T) == 1 && g.out_code != 0;      // uint8 in, bf16 / f16 out (an extension: SURVEY.md 8f-2)
+    const bool u8_unit = unit && sizeof(T) == 1 && !u8_half;
+    const size_t out_elem = u8_half ? 2 : (u8_unit ? sizeof(float) : sizeof(T));
     constexpr int W = PackOf<T>::n;
     const bool vec = (g.pixels % W == 0) && aligned_for(images, 16) && aligned_for(out, out_elem * W);
     g.vec = vec ? 1 : 0;
@@ -2285,6 +2336,21 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
         }
     }
     const T* in = static_cast<const T*>(images);
+    if constexpr (sizeof(T) == 1) {
+        if (u8_half) {
+#define SX_RUN_HALF(O)                                                                                                                                          \
+    return g.interleaved ? (vec ? run_transform<T, O, W, true>(in, static_cast<O*>(out), g, ws, sm, tmc, unit, stream)                                          \
+                                : run_transform<T, O, 1, true>(in, static_cast<O*>(out), g, ws, sm, tmc, unit, stream))                                         \
+                         : (vec ? run_transform<T, O, W>(in, static_cast<O*>(out), g, ws, sm, tmc, unit, stream)                                                \
+                                : run_transform<T, O, 1>(in, static_cast<O*>(out), g, ws, sm, tmc, unit, stream));
+            if (g.out_code == SX_BF16) {
+                SX_RUN_HALF(__hip_bfloat16)
+            } else {
+                SX_RUN_HALF(__half)
+            }
+#undef SX_RUN_HALF
+        }
+    }
     if (g.interleaved) {      // (N,H,W,3): its own instantiations, so the planar kernels carry no trace of it
         if constexpr (sizeof(T) == 1) {
             if (u8_unit) {
@@ -2489,7 +2555,9 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0, (flags & SX_MACENKO_FAST) ? 1 : 0, kChunk, 1, (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0};
+    if ((flags & (SX_MACENKO_OUT_BF16 | SX_MACENKO_OUT_F16)) != 0 && (dtype != SX_U8 || (flags & SX_MACENKO_OUT_BF16 && flags & SX_MACENKO_OUT_F16)))
+        return fail(SX_ERR_BAD_ARG, "SX_MACENKO_OUT_BF16 / SX_MACENKO_OUT_F16: uint8 input only, one of the two");
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0, (flags & SX_MACENKO_FAST) ? 1 : 0, kChunk, 1, (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0, (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0)};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -2507,7 +2575,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2534,7 +2602,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2556,7 +2624,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
@@ -2585,7 +2653,7 @@ extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* m
 // distributed pooled fit on the bracket machinery: see include/stainx_hip.h
 // ------------------------------------------------------------------------------------------------
 static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, int sample_count) {
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
     set_sampling(g);                 // local sample stride; cap per tile
     g.spread = 1;                    // also for a single local tile: the group spans other ranks
     g.cap = cap_for(g.pixels);
@@ -2597,7 +2665,7 @@ static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, 
 
 extern "C" int sx_macenko_pfit_sample_count(int64_t n, int64_t h, int64_t w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0};
+    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
     set_sampling(g);
     return g.sample_count;
 }

@@ -396,3 +396,32 @@ def test_sparse_tissue_and_blank_tiles_stay_on_the_fast_paths(dev):
         np.testing.assert_allclose(p["cov"][0].numpy(), np.cov(od), rtol=0, atol=5e-6)
         # the tile alone goes through the small-batch split and gives the same bits
         assert torch.equal(be.transform(x[5:6].to(dev), sm, tmc)[0], out[5])
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+def test_uint8_in_half_precision_out_is_the_fused_cast(dev, out_dtype):
+    """a decoder's uint8 tile becomes a model's bf16 / f16 input in one call.  The fused output is, bit for bit,
+    the reference-typed output cast with ``.to(out_dtype)`` -- planar and NHWC, raw 0-255 and /255, 16-byte packs and the scalar
+    path (odd sizes), the small-batch split and full-size work items."""
+    be = _backend(dev)
+    ref_he, ref_mc = so.macenko_fit(synth.reference_tile(96, 96).numpy())
+    sm, tmc = torch.from_numpy(ref_he), torch.from_numpy(ref_mc)
+    for n, h, w in ((3, 128, 128), (2, 33, 47), (40, 256, 256), (1, 224, 224)):
+        x = synth.he_batch(n, h, w, seed0=700 + h).to(dev)
+        for unit in (False, True):
+            want = be.transform(x, sm, tmc, normalize_to_0_1=unit).to(out_dtype)
+            got = be.transform(x, sm, tmc, normalize_to_0_1=unit, out_dtype=out_dtype)
+            assert got.dtype == out_dtype and got.shape == x.shape
+            assert torch.equal(got, want), (n, h, w, unit)
+            nhwc = be.transform(x.permute(0, 2, 3, 1).contiguous(), sm, tmc, normalize_to_0_1=unit, channels_last=True, out_dtype=out_dtype)
+            assert torch.equal(nhwc.permute(0, 3, 1, 2), want), (n, h, w, unit, "nhwc")
+    with pytest.raises(ValueError, match="out_dtype"):
+        be.transform(synth.as_dtype(synth.he_batch(1, 32, 32), torch.float32).to(dev), sm, tmc, out_dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="out_dtype"):
+        be.transform(synth.he_batch(1, 32, 32).to(dev), sm, tmc, out_dtype=torch.float64)
+    # the C ABI refuses the flag on any other input type
+    from stainx_amd import _native
+
+    xf = synth.as_dtype(synth.he_batch(1, 32, 32), torch.float32).to(dev)
+    with pytest.raises(RuntimeError, match="uint8 input only"):
+        be.transform(xf, sm, tmc, _extra_flags=_native.MACENKO_OUT_BF16)
