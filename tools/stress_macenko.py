@@ -38,11 +38,17 @@ for case in range(cases):
     if last:
         xin = xin.permute(0, 2, 3, 1).contiguous()
     out = be.transform(xin, torch.from_numpy(ref_he), torch.from_numpy(ref_mc), normalize_to_0_1=unit, channels_last=last)
+    if dt == torch.uint8:      # the fused half-precision output is the cast of this output, bit for bit (any size, layout, /255)
+        for od_t in (torch.bfloat16, torch.float16):
+            half = be.transform(xin, torch.from_numpy(ref_he), torch.from_numpy(ref_mc), normalize_to_0_1=unit, channels_last=last, out_dtype=od_t)
+            if not torch.equal(half, out.to(od_t)):
+                print(f"MISMATCH case {case}: uint8 -> {od_t} differs from the cast: n={n} {h}x{w} unit={unit} last={last}", flush=True)
+                worst["half-output mismatches"] = worst.get("half-output mismatches", 0) + 1
     if last:
         out = out.permute(0, 3, 1, 2)
     got = out.float().cpu().numpy() if out.dtype in (torch.bfloat16, torch.float16) else out.cpu().numpy()
     scale = 1.0 if unit else 255.0
-    tol = {torch.uint8: (1.0 if not unit else 1.0 / 255), torch.float16: 0.26 * scale / 255 * 4, torch.bfloat16: 2.1 * scale / 255 * 4, torch.float32: 2.55e-2 * scale / 255,
+    tol = {torch.uint8: (1.0 if not unit else (1.0 + 1e-6) / 255),      # one grey level, as a float32 quotient torch.float16: 0.26 * scale / 255 * 4, torch.bfloat16: 2.1 * scale / 255 * 4, torch.float32: 2.55e-2 * scale / 255,
            torch.float64: 2.55e-2 * scale / 255}[dt]
     # a tile whose two small covariance eigenvalues nearly coincide has no stable stain plane (in the reference either): its
     # middle eigenvector, and with it the output, moves with the last bits of the covariance -- such tiles are counted, not compared
