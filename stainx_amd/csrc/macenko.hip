@@ -711,7 +711,6 @@ struct alignas(16) TileScratch {
     uint32_t hist_c[2][256];              // candidates: one histogram per slot of the pair
     uint32_t radix_hist[256];
     uint32_t list_s[4][kShortList];
-    uint32_t list_c[2][kShortList];
     double mom[kMoments];
     double stage[64][kPartial];
     unsigned long long radix_rank, n_sel;
@@ -1704,7 +1703,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
             const uint32_t idx = u * kGroupThreads + threadIdx.x, k = pf.cand[j][u];
             if (idx < n && bin_of(k, pf.origin[j], pf.scale[j]) == b) {
                 const uint32_t at = atomicAdd(&sh->count_c[j], 1u);
-                if (at < (uint32_t)kShortList) sh->list_c[j][at] = k;
+                if (at < (uint32_t)kSample) sh->keys[j][at] = k;
             }
         }
         // big tiles / pooled groups: the rest of the candidates, eight independent loads in flight
@@ -1721,7 +1720,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
                 const uint32_t idx = base + u * kGroupThreads;
                 if (idx < n && bin_of(k[u], pf.origin[j], pf.scale[j]) == b) {
                     const uint32_t at = atomicAdd(&sh->count_c[j], 1u);
-                    if (at < (uint32_t)kShortList) sh->list_c[j][at] = k[u];
+                    if (at < (uint32_t)kSample) sh->keys[j][at] = k[u];
                 }
             }
         }
@@ -1729,7 +1728,7 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
     __syncthreads();
     {   // rank counting of the two short lists side by side, half the workgroup each
         const uint32_t per = blockDim.x / 2, j = threadIdx.x / per;
-        if ((j ? ok[1] : ok[0]) && sh->count_c[j] <= (uint32_t)kShortList) rank_pick(sh->list_c[j], sh->count_c[j], sh->rank_in_bin_c[j], threadIdx.x - j * per, per, &sh->result_c[j]);
+        if ((j ? ok[1] : ok[0]) && sh->count_c[j] <= (uint32_t)kShortList) rank_pick(sh->keys[j], sh->count_c[j], sh->rank_in_bin_c[j], threadIdx.x - j * per, per, &sh->result_c[j]);
     }
     __syncthreads();
 #pragma unroll
@@ -1739,6 +1738,12 @@ __device__ void resolve_pair(const T* __restrict__ images, const Geometry& g, co
             key_out[j] = sh->result_c[j];
         } else if (tie[j]) {
             key_out[j] = pf.lo[j];
+        } else if (ok[j] && sh->count_c[j] <= (uint32_t)kSample) {
+            // crowded bin whose keys still fit the LDS list (big tiles: 2 % of a 2048x2048 tile are 84 000 candidates, ~350 per
+            // bin on average and more where they are dense): radix rounds over the list, not over all candidates in memory
+            const uint32_t* list = sh->keys[j];
+            if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
+            key_out[j] = radix_select_stream((unsigned long long)sh->count_c[j], (unsigned long long)sh->rank_in_bin_c[j], [list](unsigned long long i, uint32_t& k) { k = list[i]; return true; }, sh);
         } else if (ok[j]) {      // crowded bin: radix rounds over the candidates
             const uint32_t* cand = ws.cand + ((size_t)group * kSlots + slot) * g.cap;
             if (threadIdx.x == 0) atomicOr(&st.fell_back, 16u << slot);
