@@ -1129,6 +1129,7 @@ template <int TPB> struct BracketScratch {
     uint32_t keys[TPB / kWave][2][kQueue];
     uint32_t hist[2][256];        // bracket-relative histogram of everything this work item queued
     uint32_t below[2];
+    uint32_t wave_n[2][TPB / kWave], base[2];      // the last flush: one reservation per slot for the whole work item
 };
 
 __device__ __forceinline__ void load_record(const StageRecord* rec, StageRecord& out) {
@@ -1250,14 +1251,25 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             }
         }
     }
-    {   // the wave's last flush: both reservations are requested before either is waited for
-        uint32_t base_a = 0, base_b = 0;
+    {   // the last flush: ONE reservation per slot for all the waves of the work item (a tile's counter is shared by all its work
+        // items: 1024 waves of a 2048x2048 tile reserving one by one made the pass twice as long as its pixels need)
         if (lane_id() == 0) {
-            if (n_a) base_a = atomicAdd(&store.ncand[s0], n_a);
-            if (n_b) base_b = atomicAdd(&store.ncand[s0 + 1], n_b);
+            sh->wave_n[0][wave] = n_a;
+            sh->wave_n[1][wave] = n_b;
         }
-        base_a = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_a);
-        base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_b);
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < TPB / kWave; ++w) total += sh->wave_n[threadIdx.x][w];
+            sh->base[threadIdx.x] = total ? atomicAdd(&store.ncand[s0 + threadIdx.x], total) : 0u;
+        }
+        __syncthreads();
+        uint32_t base_a = sh->base[0], base_b = sh->base[1];
+        for (int w = 0; w < wave; ++w) {
+            base_a += sh->wave_n[0][w];
+            base_b += sh->wave_n[1][w];
+        }
         for (uint32_t i = lane_id(); i < n_a; i += kWave) {
             const uint32_t key = queue_a[i];
             if (base_a + i < g.cap) put(&cand_a[base_a + i], key);
