@@ -121,6 +121,39 @@ __global__ __launch_bounds__(kThreads) void histogram_planar_kernel(const T* __r
     }
 }
 
+// Channels-last layout, 16-byte packs: the three channels alternate inside a pack, so three histograms are live: 16 copies of
+// each (48 KB); word (channel*256 + bin)*16 + k lies in bank 16*(bin & 1) + k, so
+// the four lanes that share a copy collide only when their bins have the same parity -- two lanes per bank on average where the
+// per-wave histograms of histogram_kernel() put five.
+constexpr int kLastCopies = 16;
+constexpr int kLastChunk = 65536;       // elements (bytes for uint8) per workgroup; a multiple of 3 * V is not needed: the channel follows e % 3
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void histogram_last_kernel(const T* __restrict__ images, int64_t total, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[3][kBins][kLastCopies];
+    for (int i = threadIdx.x; i < 3 * kBins * kLastCopies; i += kThreads) (&hist[0][0][0])[i] = 0;
+    __syncthreads();
+    constexpr int V = VecOf<T>::n;
+    const int64_t begin = (int64_t)blockIdx.x * kLastChunk, end = min(begin + (int64_t)kLastChunk, total);
+    const int copy = threadIdx.x & (kLastCopies - 1);
+    for (int64_t e = begin + (int64_t)threadIdx.x * V; e < end; e += (int64_t)kThreads * V) {
+        const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(images + e);
+        int c = (int)(e % 3);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            atomicAdd(&hist[c][grey_level<T>(pk.v[i])][copy], 1u);
+            c = c == 2 ? 0 : c + 1;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * kBins; i += kThreads) {      // thread t adds up the copies of bin t of each channel, starting at its own bank
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < kLastCopies; ++k) sum += (&hist[0][0][0])[i * kLastCopies + ((threadIdx.x + k) & (kLastCopies - 1))];
+        if (sum) atomicAdd(&counts[i], sum);
+    }
+}
+
 // torch.sum() of 256 contiguous float32 on the CPU (the reference's `counts.sum()` / `ref_hist.float().sum()`,
 // torch_backend.py:141,222): not a plain running sum -- ATen's vectorised reduction keeps four accumulators of eight lanes
 // over blocks of 32 elements, adds the accumulators in order, then the eight lanes in order.  Reproduced as is (verified
@@ -279,6 +312,8 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
         if (vec && !channels_last) {
             const int chunks_per_plane = (int)((lay.pixels + kPlaneChunk - 1) / kPlaneChunk);
             hipLaunchKernelGGL((histogram_planar_kernel<T>), dim3((unsigned)(n * 3 * chunks_per_plane)), dim3(kThreads), 0, stream, in, lay, chunks_per_plane, &tab->counts[0][0]);
+        } else if (vec && channels_last) {
+            hipLaunchKernelGGL((histogram_last_kernel<T>), dim3((unsigned)((total + kLastChunk - 1) / kLastChunk)), dim3(kThreads), 0, stream, in, total, &tab->counts[0][0]);
         } else if (vec)
             hipLaunchKernelGGL((histogram_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
         else
