@@ -24,9 +24,18 @@ int check_launch(const char* what);
 // ---- element types ----------------------------------------------------------------------------
 // Input pixels become float "unit" values exactly as the reference's dtype gate does
 // (torch_backend.py:104-113): u8 -> float(u)/255 (correctly rounded division), floats -> float(x).
+// u / 255.0f for an integer grey level u = 0..255, bit for bit the IEEE division (torch's `.float() / 255`), in three
+// instructions instead of the division's ten: q = u * c, the exact residual r = fma(-q, 255, u), q + r * c.  Checked for all 256
+// values on the device (tools/check_div255.hip).
+__device__ __forceinline__ float div255_of_level(float u) {
+    const float c = 1.0f / 255.0f;
+    const float q = u * c;
+    return fmaf(fmaf(-q, 255.0f, u), c, q);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<uint8_t> {
-    static __device__ __forceinline__ float load(uint8_t v) { return (float)v / 255.0f; }
+    static __device__ __forceinline__ float load(uint8_t v) { return div255_of_level((float)v); }
     static __device__ __forceinline__ uint8_t store(float v) { return (uint8_t)v; }  // trunc, like .to(uint8)
 };
 template <> struct Elem<__half> {

@@ -1362,7 +1362,7 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
                     // cast to the input dtype first, then /255 in that dtype (_template.py:111-112);
                     // u8 promotes to f32 (and, with SX_MACENKO_OUT_*, that f32 is cast once more: `.to(bfloat16)` fused)
                     if constexpr (sizeof(T) == 1) {
-                        res[c][i] = Elem<O>::store((float)Elem<T>::store(rgb) / 255.0f);
+                        res[c][i] = Elem<O>::store(div255_of_level((float)Elem<T>::store(rgb)));
                     } else if constexpr (sizeof(T) == 8) {
                         res[c][i] = (double)rgb / 255.0;
                     } else {
