@@ -29,11 +29,21 @@ __device__ __forceinline__ float fast_pow(float x, float e) { return exp2f(e * _
 // Centre of the LAB accumulators: keeps sum-of-squares small (values are shifted, not rescaled).
 __device__ __forceinline__ float lab_shift(int c) { return c == 0 ? 128.0f : 128.0f; }
 
-__device__ __forceinline__ void rgb_to_lab(const float rgb[3], float lab[3]) {
-    float lin[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)   // torch_backend.py:28-29
-        lin[c] = rgb[c] > 0.04045f ? fast_pow((rgb[c] + 0.055f) * (1.0f / 1.055f), 2.4f) : rgb[c] * (1.0f / 12.92f);
+__device__ __forceinline__ float srgb_to_linear(float v) {      // torch_backend.py:28-29
+    return v > 0.04045f ? fast_pow((v + 0.055f) * (1.0f / 1.055f), 2.4f) : v * (1.0f / 12.92f);
+}
+
+// uint8 pixels take one of 256 values per channel: their linear-light value comes from a table in LDS (filled with the very
+// expression above, so every pixel gets the bits it got before) instead of a division, a logarithm and an exponential each.
+struct LinearTable {
+    float lin[256];
+    __device__ __forceinline__ void fill() {
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) lin[t] = srgb_to_linear(Elem<uint8_t>::load((uint8_t)t));
+        __syncthreads();
+    }
+};
+
+__device__ __forceinline__ void linear_to_lab(const float lin[3], float lab[3]) {
     // torch_backend.py:32-38
     const float x = (0.412453f * lin[0] + 0.357580f * lin[1] + 0.180423f * lin[2]) * (1.0f / 0.95047f);
     const float y = (0.212671f * lin[0] + 0.715160f * lin[1] + 0.072169f * lin[2]);
@@ -46,6 +56,30 @@ __device__ __forceinline__ void rgb_to_lab(const float rgb[3], float lab[3]) {
     lab[0] = (116.0f * f[1] - 16.0f) * 2.55f;       // :51
     lab[1] = 500.0f * (f[0] - f[1]) + 128.0f;       // :52
     lab[2] = 200.0f * (f[1] - f[2]) + 128.0f;       // :53
+}
+
+__device__ __forceinline__ void rgb_to_lab(const float rgb[3], float lab[3]) {
+    float lin[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lin[c] = srgb_to_linear(rgb[c]);
+    linear_to_lab(lin, lab);
+}
+
+// LAB of pixel i of the loaded packs: through the table for uint8 (u holds grey levels), through the formula otherwise (unit values)
+template <typename T, int V>
+__device__ __forceinline__ void pixel_to_lab(const float (&u)[3][V], int i, const LinearTable* table, float lab[3]) {
+    if constexpr (sizeof(T) == 1) {
+        const float lin[3] = {table->lin[(int)u[0][i]], table->lin[(int)u[1][i]], table->lin[(int)u[2][i]]};
+        linear_to_lab(lin, lab);
+    } else {
+        const float rgb[3] = {u[0][i], u[1][i], u[2][i]};
+        rgb_to_lab(rgb, lab);
+    }
+}
+// (uint8: the packs are loaded as grey levels, not unit values)
+template <typename T, int V>
+__device__ __forceinline__ void load_for_lab(const T* __restrict__ p, float (&out)[V]) {
+    if constexpr (sizeof(T) == 1) load_raw<T, V>(p, out); else load_unit<T, V>(p, out);
 }
 
 __device__ __forceinline__ float f_inv(float t) { return t > 0.2068966f ? t * t * t : (t - 16.0f / 116.0f) * (1.0f / 7.787f); }   // :78-80
@@ -74,19 +108,20 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
     const int chunk_id = blockIdx.x % g.blocks_per_tile;
     const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
+    __shared__ LinearTable table;
+    if constexpr (sizeof(T) == 1) table.fill();
     double acc[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
         float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+        for (int c = 0; c < 3; ++c) load_for_lab<T, V>(img + c * g.pixels + p, u[c]);
         float s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const float rgb[3] = {u[0][i], u[1][i], u[2][i]};
             float lab[3];
-            rgb_to_lab(rgb, lab);
+            pixel_to_lab<T, V>(u, i, &table, lab);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float d = lab[c] - lab_shift(c);
@@ -182,16 +217,17 @@ __global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restri
         rs[c] = ref_std[c];
         rm[c] = ref_mean[c];
     }
+    __shared__ LinearTable table;
+    if constexpr (sizeof(T) == 1) table.fill();
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
         float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_unit<T, V>(img + c * g.pixels + p, u[c]);
+        for (int c = 0; c < 3; ++c) load_for_lab<T, V>(img + c * g.pixels + p, u[c]);
         T res[3][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const float rgb[3] = {u[0][i], u[1][i], u[2][i]};
             float lab[3], back[3];
-            rgb_to_lab(rgb, lab);
+            pixel_to_lab<T, V>(u, i, &table, lab);
 #pragma unroll
             for (int c = 0; c < 3; ++c) lab[c] = ((lab[c] - mu[c]) * sd_eps[c]) * rs[c] + rm[c];   // :349
             lab_to_rgb(lab, back);
