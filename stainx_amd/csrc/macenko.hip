@@ -197,6 +197,31 @@ __device__ __forceinline__ float optical_density(float raw) {
     return fmaf(-kLn2, log2_level<T>(raw), kLnIo);
 }
 
+// uint8 tiles: a channel takes one of 256 values, so its two per-pixel functions -- the optical density and the log2 level --
+// come from two 256-entry tables in LDS, filled with the very expressions above (every pixel gets the bits it got before):
+// a byte extract and an LDS read instead of convert + add + v_log_f32 (quarter rate) + fma per channel, pixel and pass.  The
+// uint8 passes are bound by their vector instructions, not by memory.  Pixel values then travel as integer BITS in the float
+// arrays of the loops (load_pixels<..., kBits = true>).
+template <typename T> struct LevelTables {
+    __device__ __forceinline__ void fill() {}
+};
+template <> struct LevelTables<uint8_t> {
+    float od[256], l2[256];
+    __device__ __forceinline__ void fill() {
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+            od[t] = optical_density<uint8_t>((float)t);
+            l2[t] = log2_level<uint8_t>((float)t);
+        }
+        __syncthreads();
+    }
+};
+template <typename T> __device__ __forceinline__ float od_of(float v, const LevelTables<T>& tb) {
+    if constexpr (sizeof(T) == 1) return tb.od[__float_as_uint(v)]; else return optical_density<T>(v);
+}
+template <typename T> __device__ __forceinline__ float l2_of(float v, const LevelTables<T>& tb) {
+    if constexpr (sizeof(T) == 1) return tb.l2[__float_as_uint(v)]; else return log2_level<T>(v);
+}
+
 __device__ __forceinline__ bool od_selected(const float od[3], bool use_all) {
     return use_all || (fminf(od[0], fminf(od[1], od[2])) >= kBeta);    // torch_backend.py:404-405
 }
@@ -243,19 +268,35 @@ __device__ __forceinline__ void concentration(const float od[3], const float* __
 // branch here costs the planar path dearly: uint8 146 -> 259 us/call measured).  Planar tiles: one 16-byte pack per plane.
 // Interleaved tiles (H,W,3): the 3V values lie side by side -- three packs, de-interleaved in registers (for free: the
 // indices are compile-time constants).
-template <typename T, int V, bool kInter>
+// kBits (uint8 only): the grey levels arrive as integer bits in the floats (for the LDS tables: od_of / l2_of), not converted.
+template <typename T, int V, bool kBits>
+__device__ __forceinline__ void load_values(const T* __restrict__ p, float (&out)[V]) {
+    if constexpr (kBits && sizeof(T) == 1) {
+        if constexpr (V == 1) {
+            out[0] = __uint_as_float((uint32_t)p[0]);
+        } else {
+            const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(p);
+#pragma unroll
+            for (int i = 0; i < V; ++i) out[i] = __uint_as_float((uint32_t)pk.v[i]);
+        }
+    } else {
+        load_raw<T, V>(p, out);
+    }
+}
+
+template <typename T, int V, bool kInter, bool kBits = false>
 __device__ __forceinline__ void load_pixels(const T* __restrict__ img, int64_t pixels, int64_t p, float (&u)[3][V]) {
     if constexpr (kInter) {
         float flat[3][V];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) load_raw<T, V>(img + 3 * p + k * V, flat[k]);
+        for (int k = 0; k < 3; ++k) load_values<T, V, kBits>(img + 3 * p + k * V, flat[k]);
 #pragma unroll
         for (int i = 0; i < V; ++i)
 #pragma unroll
             for (int c = 0; c < 3; ++c) u[c][i] = flat[(3 * i + c) / V][(3 * i + c) % V];
     } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_raw<T, V>(img + c * pixels + p, u[c]);
+        for (int c = 0; c < 3; ++c) load_values<T, V, kBits>(img + c * pixels + p, u[c]);
     }
 }
 
@@ -1018,7 +1059,7 @@ __device__ __forceinline__ void stats_item_all_pixels(const T* __restrict__ img,
 }
 
 template <typename T, int V, int TPB, bool kInter>
-__device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh) {
+__device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh, const LevelTables<T>& tb) {
     const int64_t p_begin = (int64_t)chunk_id * g.chunk;
     const int64_t p_end = min(p_begin + (int64_t)g.chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
@@ -1046,7 +1087,7 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
         const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
         for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
             float u[3][V];
-            load_pixels<T, V, kInter>(img, g.pixels, p, u);
+            load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p, u);
             // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
             // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
             const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset(j, shift);
@@ -1059,13 +1100,13 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
                         for (int c = 0; c < 3; ++c) raw[c] = u[c][i];
                     }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], optical_density<T>(raw[c]));
+                for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od_of<T>(raw[c], tb));
             }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float od[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
+                for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u[c][i], tb);
                 if (!by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
                     const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
                     if ((pos & mask) == sample_offset(jj, shift) && jj < sample_count) {
@@ -1160,7 +1201,7 @@ __device__ __forceinline__ void flush_queue(const uint32_t* queue, uint32_t n, u
 }
 
 template <typename T, int V, bool kConc, int TPB, bool kInter>
-__device__ void bracket_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, BracketScratch<TPB>* sh) {
+__device__ void bracket_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, BracketScratch<TPB>* sh, const LevelTables<T>& tb) {
     const int group = g.pooled ? 0 : (int)tile;
     GroupState& st = ws.state[group];
     constexpr int s0 = kConc ? 2 : 0;
@@ -1181,7 +1222,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 #pragma unroll
         for (int i = 0; i < V; ++i) next[c][i] = 0.0f;
     if (base + mine < p_end) {
-        load_pixels<T, V, kInter>(img, g.pixels, base + mine, next);
+        load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, base + mine, next);
     }
     StageRecord rec;
     load_record(&st.rec[kConc ? 1 : 0], rec);
@@ -1210,13 +1251,13 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             for (int i = 0; i < V; ++i) u[c][i] = next[c][i];
         const int64_t p_next = base + (int64_t)TPB * V + mine;
         if (p_next < p_end) {
-            load_pixels<T, V, kInter>(img, g.pixels, p_next, next);
+            load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p_next, next);
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float od[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = optical_density<T>(u[c][i]);
+            for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u[c][i], tb);
             uint32_t key_a, key_b;
             if constexpr (kConc) {
                 float c0, c1;
@@ -1309,7 +1350,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename O, int V, bool kUnit, int TPB, bool kInter>
 __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
-                                 const float* __restrict__ stain_matrix, uint4* __restrict__ stage = nullptr) {
+                                 const float* __restrict__ stain_matrix, const LevelTables<T>& tb, uint4* __restrict__ stage = nullptr) {
     const int64_t chunk = g.fine_chunk ? g.fine_chunk : g.chunk;
     const int64_t p_begin = (int64_t)chunk_id * chunk;
     const int64_t p_end = min(p_begin + chunk, g.pixels);
@@ -1346,13 +1387,13 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
 
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
         float u[3][V];
-        load_pixels<T, V, kInter>(img, g.pixels, p, u);
+        load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p, u);
         O res[3][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float l[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) l[c] = log2_level<T>(u[c][i]);
+            for (int c = 0; c < 3; ++c) l[c] = l2_of<T>(u[c][i], tb);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float x = fmaf(m[c][2], l[2], fmaf(m[c][1], l[1], fmaf(m[c][0], l[0], k[c])));
@@ -2049,24 +2090,30 @@ __device__ void scale_stage(const T* __restrict__ images, const Geometry& g, con
 template <typename T, int V, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ StatsScratch<kStreamThreads> sh;
-    stats_item<T, V, kStreamThreads, kInter>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh);
+    __shared__ LevelTables<T> tb;
+    tb.fill();
+    stats_item<T, V, kStreamThreads, kInter>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh, tb);
 }
 
 template <typename T, int V, bool kConc, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ BracketScratch<kStreamThreads> sh;
     const int per_tile = g.fine_chunk ? g.fine_blocks : g.blocks_per_tile;
-    bracket_item<T, V, kConc, kStreamThreads, kInter>(images, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, blockIdx.x, &sh);
+    __shared__ LevelTables<T> tb;
+    tb.fill();
+    bracket_item<T, V, kConc, kStreamThreads, kInter>(images, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, blockIdx.x, &sh, tb);
 }
 
 template <typename T, typename O, int V, bool kUnit, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __restrict__ images, O* __restrict__ out, Geometry g, Workspace ws, const float* __restrict__ stain_matrix) {
     const int per_tile = g.fine_chunk ? g.fine_blocks : g.blocks_per_tile;
+    __shared__ LevelTables<T> tb;
+    tb.fill();
     if constexpr (kInter && V > 1) {
         __shared__ uint4 stage[kStreamThreads * 3];      // 3 KB per wave: store_pixels_staged()
-        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix, stage);
+        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix, tb, stage);
     } else {
-        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix);
+        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix, tb);
     }
 }
 
