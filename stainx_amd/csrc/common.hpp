@@ -24,13 +24,14 @@ int check_launch(const char* what);
 // ---- element types ----------------------------------------------------------------------------
 // Input pixels become float "unit" values exactly as the reference's dtype gate does
 // (torch_backend.py:104-113): u8 -> float(u)/255 (correctly rounded division), floats -> float(x).
-// u / 255.0f for an integer grey level u = 0..255, bit for bit the IEEE division (torch's `.float() / 255`), in three
-// instructions instead of the division's ten: q = u * c, the exact residual r = fma(-q, 255, u), q + r * c.  Checked for all 256
-// values on the device (tools/check_div255.hip).
-__device__ __forceinline__ float div255_of_level(float u) {
+// x / 255.0f for 0 <= x <= 256, bit for bit the IEEE division (torch's `/ 255` on the float32 value), in three instructions
+// instead of the division's ten: q = x * c, the exact residual r = fma(-q, 255, x), q + r * c.  Checked on the device for EVERY
+// float32 in [0, 256] (1 132 462 081 values: all grey levels, all bf16 / f16 values of that range included) by
+// tools/check_div255.hip; outside that range (infinities) it is not the quotient: callers clamp first.
+__device__ __forceinline__ float div255_of_level(float x) {
     const float c = 1.0f / 255.0f;
-    const float q = u * c;
-    return fmaf(fmaf(-q, 255.0f, u), c, q);
+    const float q = x * c;
+    return fmaf(fmaf(-q, 255.0f, x), c, q);
 }
 
 template <typename T> struct Elem;

@@ -1407,7 +1407,7 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
                     } else if constexpr (sizeof(T) == 8) {
                         res[c][i] = (double)rgb / 255.0;
                     } else {
-                        res[c][i] = Elem<O>::store(Elem<T>::load(Elem<T>::store(rgb)) / 255.0f);
+                        res[c][i] = Elem<O>::store(div255_of_level(Elem<T>::load(Elem<T>::store(rgb))));      // (clamped to [0, 255] above)
                     }
                 } else if constexpr (sizeof(T) == 1 && sizeof(O) == 2) {
                     res[c][i] = Elem<O>::store((float)Elem<T>::store(rgb));      // the truncated grey level, exactly representable
