@@ -40,8 +40,10 @@ BYTES_PER_PIXEL = 24           # fp32 in + fp32 out, 3 channels
 def parse() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=25)
+    # A step is 0.2 ms.  The boxes this was measured on stall a process for ~0.1 s now and then (seen three times in some sixty
+    # timed loops): inside 100 steps that multiplies ms_per_step by five, inside 1000 steps (0.2 s) it adds half.
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--cpu-tiles", type=int, default=64, help="tiles of the workload the CPU baseline is timed on")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     return ap.parse_args()
@@ -153,6 +155,7 @@ def main() -> None:
                          "traffic": measured_traffic(), "algorithmic_bytes_per_launch": pixels * BYTES_PER_PIXEL,
                          "kernel": "all 7 launches of one sx_macenko_transform call (stats, plane, bracket<phi>, stain, bracket<conc>, scale, reconstruct)",
                          "device_ms_per_call": round(dev_ms, 4), "device_ms_std": round(dev_std, 4), "device_ms_min": round(min(step_ms), 4),
+                         "device_ms_median": round(sorted(step_ms)[len(step_ms) // 2], 4),
                          "dominant_kernel": {"name": "reconstruct_kernel", "algorithmic_bytes": pixels * BYTES_PER_PIXEL,
                                              "note": "the only launch that moves the full 24 B/px; its rocprofv3 average is in profiles/r01_final_macenko_cfg2_kernel_stats.csv"}},
         }

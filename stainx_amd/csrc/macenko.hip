@@ -1281,11 +1281,11 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
             n_a += (uint32_t)__popcll(m_a);
             n_b += (uint32_t)__popcll(m_b);
             if ((i + 1) % kCheck == 0) {      // the next kCheck pixels add at most kCheck * 64 keys
-                if (n_a > (uint32_t)(kQueue - kCheck * kWave)) {
+                if (__builtin_expect(n_a > (uint32_t)(kQueue - kCheck * kWave), 0)) {
                     flush_queue(queue_a, n_a, &store.ncand[s0], cand_a, g.cap, sh->hist[0], rec.bin_origin[0], rec.bin_scale[0]);
                     n_a = 0;
                 }
-                if (n_b > (uint32_t)(kQueue - kCheck * kWave)) {
+                if (__builtin_expect(n_b > (uint32_t)(kQueue - kCheck * kWave), 0)) {
                     flush_queue(queue_b, n_b, &store.ncand[s0 + 1], cand_b, g.cap, sh->hist[1], rec.bin_origin[1], rec.bin_scale[1]);
                     n_b = 0;
                 }
