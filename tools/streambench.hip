@@ -8,7 +8,10 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-constexpr int kTiles = 64, kPixels = 512 * 512;
+#ifndef SX_TILES
+#define SX_TILES 64      // -DSX_TILES=256: 805 MB, past the 256 MB Infinity Cache (what the kernels see on big batches)
+#endif
+constexpr int kTiles = SX_TILES, kPixels = 512 * 512;
 
 template <int kLogs, int kFma>
 __device__ __forceinline__ float work(float r, float g, float b, float acc) {
