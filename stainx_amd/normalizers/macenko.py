@@ -13,11 +13,15 @@ class Macenko(NormalizerTemplate):
     engine = "MacenkoHIP"
     fitted_slots = ("_stain_matrix", "_target_max_conc", "_concentration_matrix")      # (3,2), (2,), unused
 
-    def __init__(self, device: Any | None = None, backend: str | None = None, normalize_to_0_1: bool = False, precision: str = "stable"):
+    def __init__(self, device: Any | None = None, backend: str | None = None, normalize_to_0_1: bool = False, precision: str = "stable", *,
+                 output_dtype: Any | None = None):
         if precision not in ("stable", "fast"):
             raise ValueError(f"precision must be 'stable' or 'fast', got {precision!r}")
         self._precision = precision
         self.normalize_to_0_1 = normalize_to_0_1
+        # extension (not in the reference): uint8 tiles come out as torch.bfloat16 / torch.float16, the `.to(dtype)` of the
+        # result fused into the call; None keeps the reference's output type
+        self.output_dtype = output_dtype
         super().__init__(device=device, backend=backend)
 
     def engine_options(self) -> dict:
@@ -32,4 +36,7 @@ class Macenko(NormalizerTemplate):
 
     def call_options(self) -> dict:
         # the `/255` after the cast to the input dtype is fused into the last kernel
-        return {"normalize_to_0_1": bool(self.normalize_to_0_1)}
+        options = {"normalize_to_0_1": bool(self.normalize_to_0_1)}
+        if self.output_dtype is not None:
+            options["out_dtype"] = self.output_dtype
+        return options

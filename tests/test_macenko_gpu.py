@@ -415,6 +415,16 @@ def test_uint8_in_half_precision_out_is_the_fused_cast(dev, out_dtype):
             assert torch.equal(got, want), (n, h, w, unit)
             nhwc = be.transform(x.permute(0, 2, 3, 1).contiguous(), sm, tmc, normalize_to_0_1=unit, channels_last=True, out_dtype=out_dtype)
             assert torch.equal(nhwc.permute(0, 3, 1, 2), want), (n, h, w, unit, "nhwc")
+    # the same through the normaliser class and the module (keyword-only extension of the constructor)
+    from stainx_amd import Macenko, StainNormalizerTransform
+
+    ref = synth.reference_tile(96, 96).to(dev)
+    x = synth.he_batch(3, 224, 224, seed0=71).to(dev)
+    plain = Macenko(device=dev, normalize_to_0_1=True).fit(ref).transform(x)
+    fused = Macenko(device=dev, normalize_to_0_1=True, output_dtype=out_dtype).fit(ref)
+    assert torch.equal(fused.transform(x), plain.to(out_dtype))
+    module = StainNormalizerTransform(method="macenko", reference=ref, normalizer=fused)
+    assert torch.equal(module(x), plain.to(out_dtype))
     with pytest.raises(ValueError, match="out_dtype"):
         be.transform(synth.as_dtype(synth.he_batch(1, 32, 32), torch.float32).to(dev), sm, tmc, out_dtype=torch.bfloat16)
     with pytest.raises(ValueError, match="out_dtype"):
