@@ -59,7 +59,8 @@ const char* sx_last_error_string(void);
  * Replaces stainx_cuda_torch.macenko (bindings.cpp:33; src/stainx_cuda_torch/csrc/macenko.cu:67-266)
  * with the numerics of MacenkoTorch.transform (torch_backend.py:521-560).
  *   images_dev        (N,3,H,W) `dtype`; u8 is [0,255], floats are taken as [0,1] as is
- *   out_dev           (N,3,H,W) same dtype (f32 when dtype==SX_U8 and SX_MACENKO_NORMALIZE_0_1)
+ *   out_dev           (N,3,H,W) same dtype (f32 when dtype==SX_U8 and SX_MACENKO_NORMALIZE_0_1; bf16 / f16 when dtype==SX_U8 and
+ *                     SX_MACENKO_OUT_BF16 / SX_MACENKO_OUT_F16); (N,H,W,3) in and out with SX_MACENKO_CHANNELS_LAST
  *   stain_matrix_dev  6 floats, row-major (3,2)      target_max_conc_dev  2 floats
  */
 size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, int64_t width);
