@@ -48,6 +48,8 @@ typedef enum {
                                        SX_MACENKO_NORMALIZE_0_1 `transform(x, normalize_to_0_1).to(bfloat16)` -- so a uint8 tile from the decoder
                                        becomes a model's bf16 input with 3 bytes read and 6 written per pixel (an extension: SURVEY.md 8f-2) */
 #define SX_MACENKO_OUT_F16 64u       /* the same with float16 */
+#define SX_MACENKO_CLASSIC 16u       /* the four-pass form of the transform instead of the two-pass one (same bits; A/B runs, tests) */
+#define SX_MACENKO_SPEC_FAIL 128u    /* diagnostic: the two-pass form treats every speculation as failed (forces its slow exact path; tests) */
 #define SX_MACENKO_NO_TIE_SHORTCUT 8u /* diagnostic: do not resolve a bracket that closed on one key from its counts (forces the slow exact paths; tests) */
 #define SX_MACENKO_CHANNELS_LAST 2u /* images and output are (N,H,W,3) (decoder / PIL layout) instead of (N,3,H,W); an extension: the
                                       reference takes NCHW only and callers permute + copy first */

@@ -21,8 +21,10 @@ MACENKO_NORMALIZE_0_1 = 1
 MACENKO_CHANNELS_LAST = 2
 MACENKO_FAST = 4
 MACENKO_NO_TIE_SHORTCUT = 8
+MACENKO_CLASSIC = 16
 MACENKO_OUT_BF16 = 32
 MACENKO_OUT_F16 = 64
+MACENKO_SPEC_FAIL = 128
 MACENKO_PARAM_FLOATS = 48
 PFIT_SUMS = 1033
 PFIT_COMPACT = 32768

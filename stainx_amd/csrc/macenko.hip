@@ -76,6 +76,7 @@ struct alignas(256) GroupState {
     uint32_t ncand_seen[kSlots];  // copy kept for sx_macenko_tile_params
     int32_t use_all;
     uint32_t fell_back;           // bit s: slot s used the whole-group radix select; bit 4+s: candidate radix select
+    uint32_t spec;                // two-pass transform (macenko_twopass.hpp): kSpecSlow | kSpecHazard
     unsigned long long stamp[16]; // diagnostic: wall_clock64() at stage boundaries of the per-tile stages
 };
 
@@ -96,7 +97,27 @@ struct Geometry {
     int vec_width;                // pixels per 16-byte pack of the element type (host side, for the chunk rounding)
     int no_tie;                   // diagnostic (SX_MACENKO_NO_TIE_SHORTCUT): never resolve a closed bracket from its counts alone
     int out_code;                 // uint8 input only: SX_BF16 / SX_F16 output (SX_MACENKO_OUT_*), 0 = the reference's output type
+    int two_pass;                 // transform: the two-pass form (macenko_twopass.hpp) instead of the four passes of this file
+    int prior_units;              // two-pass: 16-pixel sectors the prior stage samples per tile
+    uint32_t cap2;                // two-pass: candidate records per tile and slot
+    uint32_t seg_cap;             // two-pass: ... of which every wave of pass A owns this many (its segment)
+    int n_seg;                    // two-pass: segments per tile = waves of pass A per tile
+    int spec_fail;                // diagnostic (SX_MACENKO_SPEC_FAIL): treat every speculation as failed -> the slow exact path
 };
+
+// Every field named: the struct is filled at half a dozen entry points.
+static Geometry make_geometry(int64_t n_tiles, int64_t pixels, int pooled) {
+    Geometry g{};
+    g.n_tiles = n_tiles;
+    g.pixels = pixels;
+    g.blocks_per_tile = (int)((pixels + kChunk - 1) / kChunk);
+    g.pooled = pooled;
+    g.sample_stride = 1;
+    g.cap = (uint32_t)kMinCap;
+    g.chunk = kChunk;
+    g.vec_width = 1;
+    return g;
+}
 
 // Pooled fit over several tiles ("spread" mode): the streaming stages keep candidates, counters and histograms per
 // tile exactly as the transform does (no counter shared by 4096 waves); between them a pair of small many-workgroup
@@ -121,6 +142,9 @@ struct Workspace {
     uint32_t* block_hist;         // [n_tiles*blocks_per_tile][2][256] bracket-relative histograms of a stage's candidates
     float* sample_od;             // [groups][3][kSample] optical density of the strided sample
     struct PoolState* pool;       // pooled fit over several tiles: group-level sums and the compacted candidates
+    struct PriorRecord* prior;    // two-pass transform: one record per tile
+    float* cand_od;               // two-pass transform: [n_tiles][kSlots][3][cap2] optical density of the candidates
+    uint32_t* seg_count;          // two-pass transform: [n_tiles][kSlots][n_seg] candidates each wave of pass A produced
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -139,6 +163,16 @@ static size_t cand_words(int64_t n_tiles, int64_t pixels) {
     return std::max((size_t)n_tiles * cap_for(pixels), (size_t)cap_for(n_tiles * pixels)) * kSlots;
 }
 
+// Two-pass transform: candidate records per tile and slot (the prior keeps ~3 % of the pixels per slot; an overflow is
+// detected and sends the slot to the slow path), and whether a tile size takes that form at all.
+constexpr int kLdsKeys = 16384;        // candidate keys of a slot the stages keep in LDS; the rest spill to the classic candidate area
+constexpr size_t kPriorRecordBytes = 256;
+static uint32_t cap2_for(int64_t pixels) {
+    const int64_t want = std::min<int64_t>(std::max<int64_t>(pixels / 4, 8192), 262144);
+    return (uint32_t)std::min<int64_t>(want, (int64_t)kLdsKeys + (int64_t)cap_for(pixels));
+}
+static bool two_pass_size(int64_t pixels) { return pixels >= 256 && pixels <= 64ll * kChunk; }      // (at most 256 waves of pass A per tile)
+
 static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
     const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
     size_t total = align_up(sizeof(GroupState) * n, 256);
@@ -147,6 +181,11 @@ static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
     total += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     total += align_up(sizeof(float) * 3 * kSample * n, 256);
     total += align_up(sizeof(PoolState), 256);
+    if (two_pass_size(pixels)) {
+        total += align_up(kPriorRecordBytes * n, 256);
+        total += align_up(sizeof(float) * 3 * kSlots * (size_t)cap2_for(pixels) * n, 256);
+        total += align_up(sizeof(uint32_t) * kSlots * 256 * n, 256);
+    }
     return total;
 }
 
@@ -167,6 +206,12 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     w.sample_od = reinterpret_cast<float*>(p);
     p += align_up(sizeof(float) * 3 * kSample * n, 256);
     w.pool = reinterpret_cast<PoolState*>(p);
+    p += align_up(sizeof(PoolState), 256);
+    w.prior = reinterpret_cast<PriorRecord*>(p);
+    p += align_up(kPriorRecordBytes * n, 256);
+    w.cand_od = reinterpret_cast<float*>(p);
+    p += align_up(sizeof(float) * 3 * kSlots * (size_t)cap2_for(pixels) * n, 256);
+    w.seg_count = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 
@@ -2299,6 +2344,13 @@ __global__ void export_params_kernel(const GroupState* __restrict__ state, int64
     for (int i = 0; i < 16; ++i) o[32 + i] = (float)((double)(st.stamp[i] - st.stamp[0]) * 0.01);   // us (100 MHz clock)
 }
 
+}  // namespace macenko
+}  // namespace sx
+#include "macenko_twopass.hpp"
+namespace sx {
+namespace macenko {
+static_assert(sizeof(PriorRecord) == kPriorRecordBytes, "workspace layout");
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -2349,6 +2401,21 @@ static int run_estimate(const T* images, const Geometry& g, const Workspace& ws,
     return check_launch("macenko estimate");
 }
 
+// The estimate of the two-pass transform (macenko_twopass.hpp): prior, ONE pass over the input, two small stages.
+template <typename T, int V, bool kInter = false>
+static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws, const float* tmc, hipStream_t stream) {
+    const unsigned n = (unsigned)g.n_tiles, grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
+    const bool quads = (g.pixels % 4 == 0) && aligned_for(images, 4 * sizeof(T));
+    if (quads)
+        hipLaunchKernelGGL((prior_kernel<T, true, kInter>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
+    else
+        hipLaunchKernelGGL((prior_kernel<T, false, kInter>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL((pass_a_kernel<T, V, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL((phi_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws);
+    hipLaunchKernelGGL((conc_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
+    return check_launch("macenko two-pass estimate");
+}
+
 template <typename T, typename O, int V, bool kInter = false>
 static int run_transform(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
     const unsigned items = (unsigned)(g.n_tiles * (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile));
@@ -2357,6 +2424,8 @@ static int run_transform(const T* images, O* out, const Geometry& g, const Works
         hipLaunchKernelGGL((stats_kernel<T, V, kInter>), dim3((unsigned)(g.n_tiles * g.blocks_per_tile)), dim3(kStreamThreads), 0, stream, images, g, ws);
         hipLaunchKernelGGL((fast_kernel<T>), dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
         rc = check_launch("macenko fast estimate");
+    } else if (g.two_pass) {
+        rc = run_two_pass<T, V, kInter>(images, g, ws, tmc, stream);
     } else {
         rc = run_estimate<T, V, kInter>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
     }
@@ -2384,6 +2453,13 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     g.vec = vec ? 1 : 0;
     g.vec_width = W;
     set_sampling(g);
+    if (g.two_pass) {
+        g.cap2 = cap2_for(g.pixels);
+        g.n_seg = g.blocks_per_tile * (kStreamThreads / kWave);
+        g.seg_cap = g.cap2 / (uint32_t)g.n_seg;
+        const int64_t n_sectors = g.pixels / 16;
+        g.prior_units = (int)std::min<int64_t>(std::max<int64_t>(n_sectors / 4, std::min<int64_t>(n_sectors, 64)), kPriorUnitsMax);
+    }
     // Small batches: with 16384-pixel work items a single 512x512 tile is 16 workgroups on 256 CUs and a bracket pass takes
     // 15 us of pure latency.  The bracket and reconstruct stages (integer counts / independent pixels: the split cannot
     // change a bit of the result) then use smaller work items -- at least two sweeps of a workgroup, aiming at ~1024 work
@@ -2621,7 +2697,16 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
     if ((flags & (SX_MACENKO_OUT_BF16 | SX_MACENKO_OUT_F16)) != 0 && (dtype != SX_U8 || (flags & SX_MACENKO_OUT_BF16 && flags & SX_MACENKO_OUT_F16)))
         return fail(SX_ERR_BAD_ARG, "SX_MACENKO_OUT_BF16 / SX_MACENKO_OUT_F16: uint8 input only, one of the two");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 0, 1, 0, (uint32_t)kMinCap, (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0, 0, 0, 0, 0, 0, (flags & SX_MACENKO_FAST) ? 1 : 0, kChunk, 1, (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0, (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0)};
+    Geometry g = make_geometry(n, h * w, 0);
+    g.interleaved = (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0;
+    g.fast = (flags & SX_MACENKO_FAST) ? 1 : 0;
+    g.no_tie = (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0;
+    g.out_code = (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0);
+    g.spec_fail = (flags & SX_MACENKO_SPEC_FAIL) ? 1 : 0;
+    {
+        static const bool env_classic = std::getenv("STAINX_MACENKO_CLASSIC") != nullptr;      // A/B switch for benchmarks
+        g.two_pass = (!g.fast && !(flags & SX_MACENKO_CLASSIC) && !env_classic && two_pass_size(g.pixels)) ? 1 : 0;
+    }
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -2639,7 +2724,7 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
+    Geometry g = make_geometry(n, h * w, 1);
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2666,7 +2751,7 @@ extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n,
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
+    Geometry g = make_geometry(n, h * w, 1);
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
@@ -2688,7 +2773,7 @@ extern "C" int sx_macenko_dfit_begin(const double* moments, void* state, void* s
 extern "C" int sx_macenko_dfit_histogram(const void* images, int dtype, int64_t n, int64_t h, int64_t w, const void* state, int stage, unsigned long long* hist_out, void* stream_ptr) {
     if (!images || !state || !hist_out) return fail(SX_ERR_BAD_ARG, "images / state / hist_out pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "bad sizes or stage");
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
+    Geometry g = make_geometry(n, h * w, 1);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const DFitState* st = static_cast<const DFitState*>(state);
     switch (dtype) {
@@ -2717,7 +2802,7 @@ extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* m
 // distributed pooled fit on the bracket machinery: see include/stainx_hip.h
 // ------------------------------------------------------------------------------------------------
 static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, int sample_count) {
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
+    Geometry g = make_geometry(n, h * w, 1);
     set_sampling(g);                 // local sample stride; cap per tile
     g.spread = 1;                    // also for a single local tile: the group spans other ranks
     g.cap = cap_for(g.pixels);
@@ -2729,7 +2814,7 @@ static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, 
 
 extern "C" int sx_macenko_pfit_sample_count(int64_t n, int64_t h, int64_t w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
-    Geometry g{n, h * w, blocks_per_tile_for(h * w), 0, 1, 1, 0, (uint32_t)kMinCap, 0, 0, 0, 0, 0, 0, 0, kChunk, 1, 0, 0};
+    Geometry g = make_geometry(n, h * w, 1);
     set_sampling(g);
     return g.sample_count;
 }

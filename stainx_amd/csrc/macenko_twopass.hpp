@@ -1,0 +1,970 @@
+// Macenko transform in TWO passes over the pixels ("speculate, then verify") -- included by macenko.hip.
+//
+// The classic path (macenko.hip) reads every tile four times because each per-tile quantity needs the one before it:
+// moments -> plane -> angle percentiles -> stain vectors -> concentration percentiles -> scale.  Here a cheap PRIOR of the
+// tile (a presample of 1024 sectors of 16 consecutive pixels: ~6 % of an fp32 512x512 tile) stands in for the quantities
+// that are not known yet while ONE pass gathers the exact moments and the few pixels that cannot be ruled out; small
+// per-tile stages then work out the exact values, and PROVE from them that nothing outside the gathered pixels could
+// have been the wanted order statistic.  A tile whose proof fails takes the slow exact path (whole-tile radix select).
+// Every number that reaches the output is computed by the same device functions, in the same order, as on the classic
+// path: the two paths agree bit for bit (tests/test_twopass_gpu.py).
+//
+//   K0 prior_kernel   one workgroup per tile: presample -> approximate plane frame F = [a0 a1 an], the two angle
+//                     brackets as four boundary DIRECTIONS in the (a0,a1) plane, and per concentration slot two end
+//                     directions with a lower threshold each                                    (~6 % of the input)
+//   K1 pass_a_kernel  the moments exactly as stats_kernel accumulates them + per pixel eight half-plane tests in the
+//                     prior frame; pixels that pass none are only counted, the others (~9 %) are queued in LDS and
+//                     written out per slot as optical-density triples                            (one read of the input)
+//   K2 phi_stage      two workgroups per tile (one per angle percentile): exact plane from the moments, exact keys of
+//                     the slot's candidates, exact order statistic, proof
+//   K3 conc_stage     two workgroups per tile (one per concentration): stain vectors, pseudo-inverse, exact keys, exact
+//                     order statistic, proof, scale
+//   reconstruct_kernel (unchanged)                                                  (one read + one write of the input)
+//
+// Why the proofs hold.  Let V be the exact plane (fp32, as the classic path computes it) and F the prior frame; with
+// M = F^-1 V the exact projection of a pixel x is t = Rt th + nu w, where th = (a0.x, a1.x), w = an.x, Rt is the 2x2
+// in-plane part of M (close to a rotation) and nu its out-of-plane row (the tilt of the prior plane, ~1e-3).
+//   * angles: a linear map with positive determinant keeps the cyclic order of directions, so "th is clockwise of the
+//     boundary d by more than m" implies "t is clockwise of Rt d" as long as m >= |nu||w| + rounding; pass A uses
+//     m = kw |w| + kx |x|_1 and the stage checks |nu| against kw and that the selected key lies strictly between the
+//     mapped boundaries.  Pixels whose angle is not safely inside (0, pi) raise a hazard flag (no wrap-around logic).
+//   * concentrations: row j of the pseudo-inverse is p = F^-T g; its in-plane part (g0,g1) is a non-negative combination
+//     alpha u1 + beta u2 of the slot's two end directions if it lies in their cone (checked), so for a pixel that
+//     failed both tests (u1.th < T1 - m, u2.th < T2 - m) the exact concentration is below alpha T1 + beta T2 =: Theta;
+//     the stage checks that the selected element is >= Theta.  The rank ORDER of a concentration depends only on the
+//     direction of the other stain vector, which is why two thresholds per slot are enough.
+#pragma once
+
+namespace sx {
+namespace macenko {
+
+constexpr int kPriorSweeps = 4;                       // 4-pixel quads a thread of the prior stage samples
+constexpr int kPriorUnitsMax = kGroupThreads / 4 * kPriorSweeps;      // sectors of 16 pixels per tile: 1024
+constexpr int kQueue2 = 512;                          // 16-byte records a wave queues in LDS before it must flush
+constexpr float kSpecSigmas = 5.0f;                   // half-width of a bracket in standard deviations of the sample quantile
+constexpr float kSpecEff = 1.0f;                      // effective (independent) samples per 16-pixel sector
+constexpr float kSpecKw = 0.05f, kSpecKx = 1e-5f;     // margin m = kw |w| + kx |x|_1
+constexpr uint32_t kSpecSlow = 1u, kSpecHazard = 2u;  // GroupState::spec bits
+constexpr int kMaxSegments = 256;                      // waves of pass A per tile (two_pass_size() keeps tiles within 64 work items)
+
+struct alignas(128) PriorRecord {
+    float a0[3], a1[3], an[3];     // prior frame: th0 = a0.x, th1 = a1.x, w = an.x
+    float bd[4][3];                // angle boundaries (dx, dy, 0): lower / upper of slot 0, lower / upper of slot 1; (0, 0) = open side
+    float cd[4][3];                // concentration tests (ux, uy, T): [2 * slot + end]
+    float kw, kx;
+    int32_t mode;                  // 0: speculate, 1: slow (the stages select over the whole tile)
+    int32_t min_first;
+    uint32_t open;                 // bit i: angle boundary i is open (nothing is excluded on that side)
+};
+
+constexpr int kPriorBins = 2048;       // fixed-range histograms of the prior stage
+struct alignas(16) PriorScratch {
+    double red[kGroupThreads / kWave][kPartial];
+    double mom[kMoments];
+    uint32_t hist[4][kPriorBins];
+    uint32_t n_kept, n_all, hazard, r_max;
+    float frame[9];
+    float bdir[4][2];
+    float cthr[4];
+    uint32_t open;
+};
+
+// One wave: the bin of a kPriorBins-bin histogram that holds 0-based rank `rank` (kPriorBins / 64 bins per lane).
+__device__ __forceinline__ uint32_t prior_pick_bin(const uint32_t* hist, uint32_t rank) {
+    constexpr int kPer = kPriorBins / kWave;
+    const int lane = (int)lane_id();
+    uint32_t mine = 0;
+#pragma unroll 8
+    for (int i = 0; i < kPer; ++i) mine += hist[kPer * lane + i];
+    const uint32_t incl = wave_scan_u32(mine);
+    const uint64_t over = __ballot(incl > rank);
+    const int owner = over ? (__ffsll((long long)over) - 1) : (kWave - 1);
+    uint32_t r = rank - (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), owner);
+    uint32_t bin = kPer * owner;
+    for (int i = 0; i < kPer - 1; ++i) {      // (uniform: every lane walks the owner's bins)
+        const uint32_t h = hist[kPer * owner + i];
+        if (r < h) break;
+        r -= h;
+        ++bin;
+    }
+    return bin;
+}
+
+// The presample: unit u is one sector (16 consecutive pixels) of cell u at a hashed offset; four lanes per sector, so a
+// thread's share of sweep s is one quad of 4 pixels.
+template <typename T, bool kVec, bool kInter>
+__device__ __forceinline__ bool prior_load(const T* __restrict__ img, const Geometry& g, int s, float (&od)[4][3]) {
+    const int tid = threadIdx.x, unit = s * (kGroupThreads / 4) + (tid >> 2);
+    const bool have = unit < g.prior_units;
+    float u[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[c][i] = 0.0f;
+    if (have) {
+        const int64_t n_sectors = g.pixels / 16;
+        const int64_t start = (int64_t)unit * n_sectors / g.prior_units, width = (int64_t)(unit + 1) * n_sectors / g.prior_units - start;
+        const int64_t sector = start + (int64_t)((((uint32_t)unit * 0x9E3779B1u) >> 8) % (uint32_t)width);
+        const int64_t p = (sector * 4 + (tid & 3)) * 4;
+        if constexpr (kVec) {
+            load_pixels<T, 4, kInter>(img, g.pixels, p, u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[3][1];
+                load_pixels<T, 1, kInter>(img, g.pixels, p + i, v);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) u[c][i] = v[c][0];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) od[i][c] = optical_density<T>(u[c][i]);
+    return have;
+}
+
+template <typename T, bool kVec, bool kInter>
+__global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
+    __shared__ PriorScratch sh;
+    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid / kWave;
+    const uint32_t lane = lane_id();
+    GroupState& st = ws.state[tile];
+    PriorRecord* pr = &ws.prior[tile];
+    const T* img = images + (int64_t)tile * 3 * g.pixels;
+    SX_STAMP(st, 0);
+    if (tid < kSlots) {
+        put(&st.ncand[tid], 0u);
+        put(&st.below[tid], 0u);
+        put(&st.ncand_seen[tid], 0u);
+    }
+    if (tid == 0) {
+        put(&st.fell_back, 0u);
+        put(&st.spec, 0u);
+        sh.n_kept = sh.n_all = sh.hazard = sh.open = sh.r_max = 0;
+    }
+    for (int i = tid; i < 4 * kPriorBins; i += kGroupThreads) (&sh.hist[0][0])[i] = 0;
+
+    // ---- first look at the sample: moments of its kept pixels (fp32 per thread: 16 pixels; fp64 beyond).  The pixels are
+    // not kept in registers across the eigen step (its fp64 code needs them all): they are read again afterwards, from L2.
+    {
+        float m[kPartial];
+#pragma unroll
+        for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < kPriorSweeps; ++s) {
+            float od[4][3];
+            const bool have = prior_load<T, kVec, kInter>(img, g, s, od);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* o = od[i];
+                const float keep = (have && od_selected(o, false)) ? 1.0f : 0.0f;
+                const float k0 = keep * o[0], k1 = keep * o[1], k2 = keep * o[2];
+                m[0] += keep;
+                m[1] += k0;
+                m[2] += k1;
+                m[3] += k2;
+                m[4] = fmaf(k0, o[0], m[4]);
+                m[5] = fmaf(k0, o[1], m[5]);
+                m[6] = fmaf(k0, o[2], m[6]);
+                m[7] = fmaf(k1, o[1], m[7]);
+                m[8] = fmaf(k1, o[2], m[8]);
+                m[9] = fmaf(k2, o[2], m[9]);
+            }
+        }
+        SX_STAMP(st, 1);
+#pragma unroll
+        for (int k = 0; k < kPartial; ++k) {
+            const double s = wave_total_f64((double)m[k]);
+            if (lane == kWave - 1) sh.red[wave][k] = s;
+        }
+    }
+    __syncthreads();
+    if (tid < kMoments) {
+        double s = 0.0;
+        if (tid < kPartial)
+            for (int w = 0; w < kGroupThreads / kWave; ++w) s += sh.red[w][tid];
+        sh.mom[tid] = s;
+    }
+    __syncthreads();
+    const int m_kept = (int)sh.mom[0];
+    SX_STAMP(st, 2);
+    if (tid < 2 && m_kept >= 3) {
+        double cov[9];
+        float vecs[6];
+        bool use_all;
+        unsigned long long n_sel;
+        plane_from_moments<true>(sh.mom, false, cov, vecs, use_all, n_sel);
+        if (tid == 0) {
+            const double x0 = vecs[0], y0 = vecs[2], z0 = vecs[4], x1 = vecs[1], y1 = vecs[3], z1 = vecs[5];
+            double nx = y0 * z1 - z0 * y1, ny = z0 * x1 - x0 * z1, nz = x0 * y1 - y0 * x1;
+            const double n2 = nx * nx + ny * ny + nz * nz;
+            const double inv = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+            sh.frame[0] = vecs[0]; sh.frame[1] = vecs[2]; sh.frame[2] = vecs[4];
+            sh.frame[3] = vecs[1]; sh.frame[4] = vecs[3]; sh.frame[5] = vecs[5];
+            sh.frame[6] = (float)(nx * inv); sh.frame[7] = (float)(ny * inv); sh.frame[8] = (float)(nz * inv);
+        }
+    }
+    __syncthreads();
+    auto give_up = [&]() {      // uniform: the stages select over the whole tile
+        if (tid == 0) {
+            put(&pr->mode, 1);
+            put(&st.spec, kSpecSlow);
+        }
+    };
+    if (m_kept < 3 || g.pixels < 16) {
+        give_up();
+        return;
+    }
+    SX_STAMP(st, 3);
+    float fr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fr[i] = sh.frame[i];
+    // ---- second look: plane coordinates of the sample; the angle histogram takes ONE pixel per quad (pixel s of sweep s:
+    // the four are neighbours with nearly the same key, and LDS atomics on neighbours' bins serialise)
+    float t0[kPriorSweeps][4], t1[kPriorSweeps][4];
+    uint32_t have_bits = 0, sub_kept = 0;      // bit s: the thread has a quad in sweep s / its histogram pixel passes the OD filter
+    {
+        uint32_t cnt = 0, all = 0, haz = 0;
+        float r_max = 0.0f;
+#pragma unroll
+        for (int s = 0; s < kPriorSweeps; ++s) {
+            float od[4][3];
+            const bool have = prior_load<T, kVec, kInter>(img, g, s, od);
+            if (have) have_bits |= 1u << s;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* o = od[i];
+                t0[s][i] = fmaf(o[2], fr[2], fmaf(o[1], fr[1], o[0] * fr[0]));
+                t1[s][i] = fmaf(o[2], fr[5], fmaf(o[1], fr[4], o[0] * fr[3]));
+                if (have) {
+                    r_max = fmaxf(r_max, fabsf(t0[s][i]) + fabsf(t1[s][i]));
+                    if (i == s) ++all;
+                    if (od_selected(o, false)) {
+                        if (!(t1[s][i] - 0.05f * fabsf(t0[s][i]) > 0.0f)) haz = 1;
+                        if (i == s) {
+                            ++cnt;
+                            sub_kept |= 1u << s;
+                        }
+                    }
+                }
+            }
+        }
+        cnt = wave_total_u32(cnt);
+        all = wave_total_u32(all);
+        const uint32_t rm = wave_max_u32(__float_as_uint(r_max));      // non-negative floats order like their bits
+        const uint64_t hz = __ballot(haz != 0);
+        if (lane == 0) {
+            if (cnt) atomicAdd(&sh.n_kept, cnt);
+            atomicAdd(&sh.n_all, all);
+            atomicMax(&sh.r_max, rm);
+            if (hz) atomicOr(&sh.hazard, 1u);
+        }
+        // a kept pixel without a hazard has th1 > 0: its diamond key lies in (0, 2)
+#pragma unroll
+        for (int s = 0; s < kPriorSweeps; ++s)
+            if ((sub_kept >> s) & 1u) {
+                const float d = diamond_angle(t1[s][s], t0[s][s]);
+                atomicAdd(&sh.hist[0][min((uint32_t)fmaxf(d * (float)(kPriorBins / 2), 0.0f), (uint32_t)(kPriorBins - 1))], 1u);
+            }
+    }
+    __syncthreads();
+    SX_STAMP(st, 4);
+    if (sh.hazard) {
+        give_up();
+        return;
+    }
+    const int mv = (int)sh.n_kept, ms = (int)sh.n_all;
+    if (wave < 4) {      // query `wave`: lower / upper boundary of slot 0, lower / upper boundary of slot 1
+        const float f = wave < 2 ? 0.01f : 0.99f;
+        const float n_eff = fmaxf((float)mv * (kSpecEff / 4.0f), 4.0f);      // four histogram pixels per sector
+        const float sd = sqrtf(f * (1.0f - f) / n_eff);
+        const bool upper = (wave & 1) != 0;
+        const float level = upper ? f + kSpecSigmas * sd : f - kSpecSigmas * sd;
+        const bool open = mv < 16 || (upper ? level >= 1.0f : level <= 0.0f);
+        const float pos = fminf(fmaxf(level, 0.0f), 1.0f) * (float)max(mv - 1, 0);
+        const uint32_t rank = (uint32_t)min(max((int)(upper ? ceilf(pos) : floorf(pos)), 0), max(mv - 1, 0));
+        const uint32_t b = prior_pick_bin(sh.hist[0], rank);
+        if (lane == 0) {
+            // the bin's outer edge; an open side still needs a direction for the concentration tests: the range's end
+            float d = upper ? (float)(b + 1) * (2.0f / kPriorBins) : (float)b * (2.0f / kPriorBins);
+            if (open) d = upper ? 1.98f : 0.02f;
+            d = fminf(fmaxf(d, 0.02f), 1.98f);
+            float c, s;
+            direction_from_key(float_key(d), c, s);
+            sh.bdir[wave][0] = c;
+            sh.bdir[wave][1] = s;
+            if (open) atomicOr(&sh.open, 1u << wave);
+        }
+    }
+    __syncthreads();
+    SX_STAMP(st, 5);
+    // ---- concentration tests: two end directions per slot, a lower threshold each
+    float bd[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bd[q][0] = sh.bdir[q][0];
+        bd[q][1] = sh.bdir[q][1];
+    }
+    // which percentile vector is hematoxylin: the one with the larger first component (torch_backend.py:439), judged at the
+    // middle of the brackets (the stage checks the exact vectors against the cone the choice implies)
+    const float lo_c = bd[0][0] + bd[1][0], lo_s = bd[0][1] + bd[1][1], hi_c = bd[2][0] + bd[3][0], hi_s = bd[2][1] + bd[3][1];
+    const bool min_first = (fr[0] * lo_c + fr[3] * lo_s) * __builtin_amdgcn_rsqf(lo_c * lo_c + lo_s * lo_s) > (fr[0] * hi_c + fr[3] * hi_s) * __builtin_amdgcn_rsqf(hi_c * hi_c + hi_s * hi_s);
+    float cu[4][2];      // [2 * slot + end]
+    {
+        // perpendicular to the LOW vector, positive towards larger angles: (-s, c); to the HIGH vector, towards smaller: (s, -c)
+        const int slot_perp_high = min_first ? 0 : 1, slot_perp_low = 1 - slot_perp_high;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            cu[2 * slot_perp_high + e][0] = bd[2 + e][1];
+            cu[2 * slot_perp_high + e][1] = -bd[2 + e][0];
+            cu[2 * slot_perp_low + e][0] = -bd[e][1];
+            cu[2 * slot_perp_low + e][1] = bd[e][0];
+        }
+    }
+    // keys u . th lie in [-r_max, r_max]; the wanted quantile is far up the positive side: bins over [0, r_max], the rest in bin 0
+    const float r_max = __uint_as_float(sh.r_max);
+    const float c_scale = r_max > 0.0f ? (float)kPriorBins / r_max : 0.0f;
+    for (int i = tid; i < kPriorBins; i += kGroupThreads) sh.hist[0][i] = 0;      // (the angle histogram has been read)
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < kPriorSweeps; ++s)
+            if ((have_bits >> s) & 1u) {
+                const float k = fmaf(cu[q][0], t0[s][s], cu[q][1] * t1[s][s]);
+                atomicAdd(&sh.hist[q][min((uint32_t)fmaxf(k * c_scale, 0.0f), (uint32_t)(kPriorBins - 1))], 1u);
+            }
+    __syncthreads();
+    SX_STAMP(st, 6);
+    if (wave < 4) {
+        const float n_eff = fmaxf((float)ms * (kSpecEff / 4.0f), 4.0f);
+        const float level = 0.99f - kSpecSigmas * sqrtf(0.99f * 0.01f / n_eff);
+        const uint32_t rank = (uint32_t)max((int)floorf(fmaxf(level, 0.0f) * (float)max(ms - 1, 0)), 0);
+        const uint32_t b = prior_pick_bin(sh.hist[wave], rank);
+        if (lane == 0) sh.cthr[wave] = (level > 0.0f && b > 0) ? (float)b * (r_max / (float)kPriorBins) : -__builtin_huge_valf();      // the bin's lower edge
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            put(&pr->a0[i], sh.frame[i]);
+            put(&pr->a1[i], sh.frame[3 + i]);
+            put(&pr->an[i], sh.frame[6 + i]);
+        }
+        const uint32_t open = sh.open;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool is_open = ((open >> q) & 1u) != 0;      // the zero direction: pass A excludes nothing on that side
+            put(&pr->bd[q][0], is_open ? 0.0f : bd[q][0]);
+            put(&pr->bd[q][1], is_open ? 0.0f : bd[q][1]);
+            put(&pr->bd[q][2], 0.0f);
+            put(&pr->cd[q][0], cu[q][0]);
+            put(&pr->cd[q][1], cu[q][1]);
+            put(&pr->cd[q][2], sh.cthr[q]);
+        }
+        put(&pr->kw, kSpecKw);
+        put(&pr->kx, kSpecKx);
+        put(&pr->mode, 0);
+        put(&pr->min_first, min_first ? 1 : 0);
+        put(&pr->open, open);
+    }
+    SX_STAMP(st, 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: the one pass over the input that the estimate needs
+// ------------------------------------------------------------------------------------------------
+template <int TPB> struct PassAScratch {
+    StatsScratch<TPB> stats;
+    uint4 queue[TPB / kWave][kQueue2];
+    uint32_t below[2], hazard;
+};
+
+// Moves the records a wave queued to its own SEGMENT of the tile's per-slot candidate arrays (record i goes to slot s iff
+// bit s of its flag word is set).  Every wave of a tile owns entries [k seg_cap, (k+1) seg_cap) of each slot, k = 4 * work
+// item + wave: no reservation, no atomic, nothing another wave waits for -- with a counter shared by the tile, a flush in
+// the middle of the pixel loop cost four returning atomics one after the other, ~10 us per wave.  `have[s]` counts what the
+// wave has produced so far (it may pass seg_cap: the stage sees that and takes the slow path for the slot).
+__device__ __forceinline__ void write_records(const uint4* __restrict__ queue, uint32_t n, uint32_t (&have)[kSlots], float* __restrict__ cand_tile, uint32_t cap2, uint32_t seg_base, uint32_t seg_cap) {
+    for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
+        const uint32_t i = i0 + lane_id();
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        if (i < n) rec = queue[i];
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const bool has = ((rec.w >> s) & 1u) != 0;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(has);
+            if (has) {
+                const uint32_t at = have[s] + rank_in_mask(mask);
+                if (at < seg_cap) {
+                    float* dst = cand_tile + (size_t)s * 3 * cap2 + seg_base + at;
+                    put(&dst[0], __uint_as_float(rec.x));
+                    put(&dst[cap2], __uint_as_float(rec.y));
+                    put(&dst[2 * (size_t)cap2], __uint_as_float(rec.z));
+                }
+            }
+            have[s] += (uint32_t)__popcll(mask);
+        }
+    }
+}
+
+template <typename T, int V, int TPB, bool kInter>
+__device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, PassAScratch<TPB>* sh, const LevelTables<T>& tb) {
+    const int64_t p_begin = (int64_t)chunk_id * g.chunk;
+    const int64_t p_end = min(p_begin + (int64_t)g.chunk, g.pixels);
+    const T* img = images + tile * 3 * g.pixels;
+    GroupState& st = ws.state[tile];
+    const PriorRecord* __restrict__ pr = &ws.prior[tile];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const bool speculate = get(&pr->mode) == 0;
+    // the prior record: uniform values (scalar registers)
+    float a0[3], a1[3], an[3], bd[4][3], cd[4][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a0[i] = get(&pr->a0[i]);
+        a1[i] = get(&pr->a1[i]);
+        an[i] = get(&pr->an[i]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bd[q][i] = get(&pr->bd[q][i]);
+            cd[q][i] = get(&pr->cd[q][i]);
+        }
+    const float kw = get(&pr->kw), kx = get(&pr->kx);
+    if (threadIdx.x < 2) sh->below[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sh->hazard = 0;
+
+    constexpr int kShortRun = 32 / V > 0 ? 32 / V : 1;      // packs per fp32 run -- the grouping of stats_item, bit for bit
+    double acc[kPartial];
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) acc[k] = 0.0;
+    float m[kPartial];
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
+
+    uint4* queue = sh->queue[wave];
+    uint32_t n_q = 0, have[kSlots] = {0u, 0u, 0u, 0u}, below_a = 0, below_b = 0;
+    uint64_t hazard = 0;
+    float* cand_tile = ws.cand_od + (size_t)tile * kSlots * 3 * g.cap2;
+    const uint32_t seg = (uint32_t)chunk_id * (TPB / kWave) + (uint32_t)wave, seg_base = seg * g.seg_cap;
+    auto flush = [&]() {
+        write_records(queue, n_q, have, cand_tile, g.cap2, seg_base, g.seg_cap);
+        n_q = 0;
+    };
+
+    const int64_t mine = (int64_t)threadIdx.x * V;
+    float next[3][V];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < V; ++i) next[c][i] = 0.0f;
+    if (p_begin + mine < p_end) load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p_begin + mine, next);
+    __syncthreads();      // the scratch words above
+
+    int in_run = 0;
+    for (int64_t base_p = p_begin; base_p < p_end; base_p += (int64_t)TPB * V) {
+        const bool live = base_p + mine < p_end;
+        float u[3][V];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < V; ++i) u[c][i] = next[c][i];
+        const int64_t p_next = base_p + (int64_t)TPB * V + mine;
+        if (p_next < p_end) load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p_next, next);
+        const uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float od[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u[c][i], tb);
+            const bool kept = live && od_selected(od, false);
+            if (kept) {      // (stats_item multiplies by a 0 / 1 `keep` instead: the same bits, four instructions more)
+                m[0] += 1.0f;
+                m[1] += od[0];
+                m[2] += od[1];
+                m[3] += od[2];
+                m[4] = fmaf(od[0], od[0], m[4]);
+                m[5] = fmaf(od[0], od[1], m[5]);
+                m[6] = fmaf(od[0], od[2], m[6]);
+                m[7] = fmaf(od[1], od[1], m[7]);
+                m[8] = fmaf(od[1], od[2], m[8]);
+                m[9] = fmaf(od[2], od[2], m[9]);
+            }
+            if (speculate) {
+                const float t0 = fmaf(od[2], a0[2], fmaf(od[1], a0[1], od[0] * a0[0]));
+                const float t1 = fmaf(od[2], a1[2], fmaf(od[1], a1[1], od[0] * a1[0]));
+                const float w = fmaf(od[2], an[2], fmaf(od[1], an[1], od[0] * an[0]));
+                const float mrg = fmaf(kw, fabsf(w), kx * (fabsf(od[0]) + fabsf(od[1]) + fabsf(od[2])));
+                const uint64_t valid = __builtin_amdgcn_ballot_w64(kept);
+                // angle slots: cross(d, th) = dx th1 - dy th0 > 0 iff th is counter-clockwise of d (a larger angle); "below" is
+                // cross < -m, "above" cross > m, the margin folded into the multiply-adds; an open side has d = 0: never true
+                const uint64_t lt_a = __builtin_amdgcn_ballot_w64(fmaf(bd[0][0], t1, fmaf(-bd[0][1], t0, mrg)) < 0.0f);
+                const uint64_t gt_a = __builtin_amdgcn_ballot_w64(fmaf(bd[1][0], t1, fmaf(-bd[1][1], t0, -mrg)) > 0.0f);
+                const uint64_t lt_b = __builtin_amdgcn_ballot_w64(fmaf(bd[2][0], t1, fmaf(-bd[2][1], t0, mrg)) < 0.0f);
+                const uint64_t gt_b = __builtin_amdgcn_ballot_w64(fmaf(bd[3][0], t1, fmaf(-bd[3][1], t0, -mrg)) > 0.0f);
+                hazard |= valid & ~__builtin_amdgcn_ballot_w64(fmaf(-0.05f, fabsf(t0), t1) > mrg);
+                below_a += (uint32_t)__popcll(valid & lt_a);
+                below_b += (uint32_t)__popcll(valid & lt_b);
+                const uint64_t c_a = valid & ~lt_a & ~gt_a, c_b = valid & ~lt_b & ~gt_b;
+                // concentration slots: every pixel takes part; a candidate passes the threshold at either end direction
+                const uint64_t c_c = live_mask & (__builtin_amdgcn_ballot_w64(fmaf(cd[0][0], t0, fmaf(cd[0][1], t1, mrg)) >= cd[0][2]) |
+                                                  __builtin_amdgcn_ballot_w64(fmaf(cd[1][0], t0, fmaf(cd[1][1], t1, mrg)) >= cd[1][2]));
+                const uint64_t c_d = live_mask & (__builtin_amdgcn_ballot_w64(fmaf(cd[2][0], t0, fmaf(cd[2][1], t1, mrg)) >= cd[2][2]) |
+                                                  __builtin_amdgcn_ballot_w64(fmaf(cd[3][0], t0, fmaf(cd[3][1], t1, mrg)) >= cd[3][2]));
+                const uint64_t any = c_a | c_b | c_c | c_d;
+                if (any) {      // wave-uniform
+                    uint32_t flags = __builtin_amdgcn_inverse_ballot_w64(c_a) ? 1u : 0u;
+                    flags |= __builtin_amdgcn_inverse_ballot_w64(c_b) ? 2u : 0u;
+                    flags |= __builtin_amdgcn_inverse_ballot_w64(c_c) ? 4u : 0u;
+                    flags |= __builtin_amdgcn_inverse_ballot_w64(c_d) ? 8u : 0u;
+                    if (__builtin_amdgcn_inverse_ballot_w64(any)) queue[n_q + rank_in_mask(any)] = make_uint4(__float_as_uint(od[0]), __float_as_uint(od[1]), __float_as_uint(od[2]), flags);
+                    n_q += (uint32_t)__popcll(any);
+                }
+                if (__builtin_expect(n_q > (uint32_t)(kQueue2 - kWave), 0)) flush();      // the next pixel adds at most 64 records
+            }
+        }
+        if (++in_run == kShortRun) {
+#pragma unroll
+            for (int k = 0; k < kPartial; ++k) {
+                acc[k] += (double)m[k];
+                m[k] = 0.0f;
+            }
+            in_run = 0;
+        }
+    }
+    if (in_run) {
+#pragma unroll
+        for (int k = 0; k < kPartial; ++k) acc[k] += (double)m[k];
+    }
+
+    // ---- the work item's partial moments: exactly the reduction of stats_item
+    StatsScratch<TPB>* ss = &sh->stats;
+#pragma unroll
+    for (int k = 0; k < kPartial; ++k) {
+        const double s = wave_total_f64(acc[k]);
+        if (lane_id() == kWave - 1) ss->red[wave][k] = s;
+    }
+    if (speculate) {
+        flush();
+        if (lane_id() == 0) {
+            uint32_t* counts = ws.seg_count + ((size_t)tile * kSlots) * g.n_seg + seg;
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) put(&counts[(size_t)s * g.n_seg], have[s]);
+            if (below_a) atomicAdd(&sh->below[0], below_a);
+            if (below_b) atomicAdd(&sh->below[1], below_b);
+            if (hazard) atomicOr(&sh->hazard, 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartial) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < TPB / kWave; ++w) s += ss->red[w][threadIdx.x];
+        put(&ws.partial[item * kPartial + threadIdx.x], s);
+    }
+    if (speculate && threadIdx.x == kPartial) {      // (no value comes back: nothing waits for these)
+        if (sh->below[0]) atomicAdd(&st.below[0], sh->below[0]);
+        if (sh->below[1]) atomicAdd(&st.below[1], sh->below[1]);
+        if (sh->hazard) atomicOr(&st.spec, kSpecHazard);
+    }
+    double kept_total = 0.0;
+#pragma unroll
+    for (int w = 0; w < TPB / kWave; ++w) kept_total += ss->red[w][0];      // workgroup-uniform
+    // (see stats_item: a work item without kept pixels also leaves the moments of ALL its pixels)
+    if (__builtin_expect(kept_total < 3.0, 0)) stats_item_all_pixels<T, V, TPB, kInter>(img, g.pixels, p_begin, p_end, ws.partial_all + item * kPartial, ss);
+}
+
+template <typename T, int V, bool kInter = false>
+__global__ __launch_bounds__(kStreamThreads) void pass_a_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
+    __shared__ PassAScratch<kStreamThreads> sh;
+    __shared__ LevelTables<T> tb;
+    tb.fill();
+    pass_a_item<T, V, kStreamThreads, kInter>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh, tb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 / K3: exact order statistic of one slot from its candidates, and the proof that it is the tile's
+// ------------------------------------------------------------------------------------------------
+struct alignas(16) SlotScratch {
+    TileScratch t;                     // radix_select_stream / rank_pick machinery; t.keys is the list of the picked bin
+    uint32_t keys[kLdsKeys];
+    float vecs[6], pinv[6], he[6];
+    double check[8];
+    uint32_t lo, hi, n_list, bin, rank_in_bin, result;
+    int ok, use_all;
+    unsigned long long n_sel;
+    uint32_t seg_prefix[kMaxSegments + 1], seg_total, seg_overflow;
+};
+
+// The slot's candidates lie in one segment per wave of pass A: prefix sums of the segment fills (one wave, four segments per
+// lane), so that candidate i of the slot is entry i - prefix[k] of segment k.  Needs a barrier before the prefix is used.
+__device__ __forceinline__ void segment_prefix(SlotScratch* sh, const Geometry& g, const Workspace& ws, int tile, int slot) {
+    if (threadIdx.x < kWave) {
+        const uint32_t* counts = ws.seg_count + ((size_t)tile * kSlots + slot) * g.n_seg;
+        uint32_t c[4], sum = 0, raw = 0, over = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * (int)threadIdx.x + u;
+            const uint32_t v = k < g.n_seg ? get(&counts[k]) : 0u;
+            raw += v;
+            over |= v > g.seg_cap ? 1u : 0u;
+            c[u] = min(v, g.seg_cap);
+            sum += c[u];
+        }
+        const uint32_t incl = wave_scan_u32(sum);
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * (int)threadIdx.x + u;
+            if (k <= g.n_seg) sh->seg_prefix[k] = run;
+            run += c[u];
+        }
+        const uint32_t total_raw = wave_total_u32(raw);
+        const uint64_t any_over = __ballot(over != 0);
+        if (threadIdx.x == kWave - 1) {
+            sh->seg_prefix[g.n_seg] = incl;      // (n_seg <= 4 * 64: the last lane's inclusive sum is the total)
+            sh->seg_total = total_raw;
+            sh->seg_overflow = any_over ? 1u : 0u;
+        }
+    }
+}
+// Every candidate of the slot once: a team of blockDim / n_seg consecutive threads per segment, four loads per plane in flight
+// per thread (a plain one-record-per-iteration loop pays one memory latency per record: 7-9 us per stage).  fn(i, od): i is
+// the candidate's index in the slot (segments in order), od its optical density.
+template <class Fn>
+__device__ __forceinline__ void for_each_candidate(const SlotScratch* sh, const Geometry& g, const float* __restrict__ c0, Fn fn) {
+    const uint32_t team = blockDim.x / (uint32_t)g.n_seg, k = threadIdx.x / team, r = threadIdx.x - k * team;
+    if (k >= (uint32_t)g.n_seg) return;
+    const uint32_t first = sh->seg_prefix[k], cnt = sh->seg_prefix[k + 1] - first;
+    const float* src = c0 + (size_t)k * g.seg_cap;
+    constexpr int kFlight = 4;
+    for (uint32_t off = r; off < cnt; off += team * kFlight) {
+        float od[kFlight][3];
+#pragma unroll
+        for (int u = 0; u < kFlight; ++u) {
+            const uint32_t o = off + u * team;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) od[u][c] = o < cnt ? get(&src[(size_t)c * g.cap2 + o]) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < kFlight; ++u) {
+            const uint32_t o = off + u * team;
+            if (o < cnt) fn(first + o, od[u]);
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t slot_key(const SlotScratch* sh, const uint32_t* __restrict__ spill, uint32_t i) { return i < (uint32_t)kLdsKeys ? sh->keys[i] : get(&spill[i - kLdsKeys]); }
+
+// exact element of 0-based rank `rank` among the n keys of the slot (n >= 1, rank < n); whole workgroup, uniform result
+__device__ uint32_t select_slot_keys(SlotScratch* sh, const uint32_t* __restrict__ spill, uint32_t n, uint32_t rank) {
+    const uint32_t lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    if (threadIdx.x == 0) {
+        sh->lo = 0xFFFFFFFFu;
+        sh->hi = 0u;
+        sh->n_list = 0;
+        sh->result = 0;
+    }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) sh->t.hist_c[0][i] = 0;
+    __syncthreads();
+    {
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t k = slot_key(sh, spill, i);
+            mn = min(mn, k);
+            mx = max(mx, k);
+        }
+        mn = wave_min_u32(mn);
+        mx = wave_max_u32(mx);
+        if (lane == 0 && mn != 0xFFFFFFFFu) {
+            atomicMin(&sh->lo, mn);
+            atomicMax(&sh->hi, mx);
+        }
+    }
+    __syncthreads();
+    const double origin = bin_origin_for(sh->lo), scale = bin_scale_for(sh->lo, sh->hi);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&sh->t.hist_c[0][bin_of(slot_key(sh, spill, i), origin, scale)], 1u);
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t b, rb;
+        scan_pick32(sh->t.hist_c[0], rank, b, rb);
+        if (lane == 0) {
+            sh->bin = b;
+            sh->rank_in_bin = rb;
+        }
+    }
+    __syncthreads();
+    const uint32_t b = sh->bin;
+    uint32_t* list = &sh->t.keys[0][0];      // 2 * kSample entries
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t k = slot_key(sh, spill, i);
+        if (bin_of(k, origin, scale) == b) {
+            const uint32_t at = atomicAdd(&sh->n_list, 1u);
+            if (at < (uint32_t)(2 * kSample)) list[at] = k;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_list = sh->n_list, want = sh->rank_in_bin;
+    if (__builtin_expect(n_list <= (uint32_t)kShortList, 1)) {
+        rank_pick(list, n_list, want, threadIdx.x, blockDim.x, &sh->result);
+        __syncthreads();
+        return sh->result;
+    }
+    if (n_list <= (uint32_t)(2 * kSample)) return radix_select_stream((unsigned long long)n_list, (unsigned long long)want, [list](unsigned long long i, uint32_t& k) { k = list[i]; return true; }, &sh->t);
+    // a bin with more keys than the list holds (heavy ties): radix rounds over all the keys
+    return radix_select_stream((unsigned long long)n, (unsigned long long)rank, [sh, spill](unsigned long long i, uint32_t& k) { k = slot_key(sh, spill, (uint32_t)i); return true; }, &sh->t);
+}
+
+// M = F^-1 X for the 3x3 frame F = [a0 a1 an] (columns) and the three-vector X: coordinates of X in the prior frame (fp64)
+__device__ inline void frame_coordinates(const PriorRecord* pr, const double x[3], double out[3]) {
+    const double f00 = pr->a0[0], f10 = pr->a0[1], f20 = pr->a0[2];
+    const double f01 = pr->a1[0], f11 = pr->a1[1], f21 = pr->a1[2];
+    const double f02 = pr->an[0], f12 = pr->an[1], f22 = pr->an[2];
+    const double c00 = f11 * f22 - f12 * f21, c01 = f12 * f20 - f10 * f22, c02 = f10 * f21 - f11 * f20;
+    const double det = f00 * c00 + f01 * c01 + f02 * c02;
+    const double inv = det != 0.0 ? 1.0 / det : 0.0;
+    // inverse = adj / det, adj = cofactor^T
+    const double i00 = c00 * inv, i01 = (f02 * f21 - f01 * f22) * inv, i02 = (f01 * f12 - f02 * f11) * inv;
+    const double i10 = c01 * inv, i11 = (f00 * f22 - f02 * f20) * inv, i12 = (f02 * f10 - f00 * f12) * inv;
+    const double i20 = c02 * inv, i21 = (f01 * f20 - f00 * f21) * inv, i22 = (f00 * f11 - f01 * f10) * inv;
+    out[0] = i00 * x[0] + i01 * x[1] + i02 * x[2];
+    out[1] = i10 * x[0] + i11 * x[1] + i12 * x[2];
+    out[2] = i20 * x[0] + i21 * x[1] + i22 * x[2];
+}
+
+// the tile's moments summed in the order plane_stage uses (index order; bit for bit the same doubles), then the plane
+template <typename T>
+__device__ void exact_plane(const Geometry& g, const Workspace& ws, int tile, SlotScratch* sh) {
+    const int64_t first = (int64_t)tile * g.blocks_per_tile;
+    if (threadIdx.x < kPartial) {
+        double running = 0.0;
+        for (int64_t b = 0; b < g.blocks_per_tile; ++b) running += get(&ws.partial[(first + b) * kPartial + threadIdx.x]);
+        sh->t.mom[threadIdx.x] = running;
+    }
+    if (threadIdx.x == kPartial) sh->t.mom[kPartial] = (double)g.pixels;
+    if (threadIdx.x > kPartial && threadIdx.x < kMoments) sh->t.mom[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (__builtin_expect(sh->t.mom[0] < 3.0, 0)) {      // uniform, rare: every work item of such a tile left its all-pixel sums
+        __syncthreads();
+        if (threadIdx.x < kPartial) {
+            double running = 0.0;
+            for (int64_t b = 0; b < g.blocks_per_tile; ++b) running += get(&ws.partial_all[(first + b) * kPartial + threadIdx.x]);
+            sh->t.mom[kPartial + threadIdx.x] = running;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) {
+        double cov[9];
+        bool use_all;
+        unsigned long long n_sel;
+        float vecs[6];
+        plane_from_moments<true>(sh->t.mom, true, cov, vecs, use_all, n_sel);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sh->vecs[i] = vecs[i];
+            sh->use_all = use_all ? 1 : 0;
+            sh->n_sel = n_sel;
+            if ((blockIdx.x & 1) == 0) {
+                GroupState& st = ws.state[tile];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    put(&st.vecs[i], vecs[i]);
+                    put(&st.rec[0].coef[i], vecs[i]);
+                }
+#pragma unroll
+                for (int k = 0; k < kMoments; ++k) put(&st.mom[k], sh->t.mom[k]);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) put(&st.cov[i], cov[i]);
+                put(&st.use_all, use_all ? 1 : 0);
+                put(&st.rec[0].use_all, use_all ? 1 : 0);
+                put(&st.n_sel, n_sel);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGroupThreads) void phi_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
+    __shared__ SlotScratch sh;
+    const int tile = blockIdx.x >> 1, j = blockIdx.x & 1;
+    GroupState& st = ws.state[tile];
+    const PriorRecord* pr = &ws.prior[tile];
+    const uint32_t below = get(&st.below[j]), spec = get(&st.spec);
+    const int mode = get(&pr->mode);
+    const bool stamps = j == 0;
+    if (stamps) SX_STAMP(st, 8);
+    segment_prefix(&sh, g, ws, tile, j);
+    exact_plane<T>(g, ws, tile, &sh);
+    if (stamps) SX_STAMP(st, 9);
+    const uint32_t n = sh.seg_prefix[g.n_seg], n_raw = sh.seg_total;
+    const bool use_all = sh.use_all != 0;
+    const unsigned long long n_sel = sh.n_sel;
+    const unsigned long long rank = nearest_rank_index(j ? 99.0 : 1.0, n_sel);      // alpha = 1 (torch_backend.py:421-422)
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = sh.vecs[i];
+    bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !use_all && !g.spec_fail && sh.seg_overflow == 0 && rank >= below && rank - below < n;
+    uint32_t* spill = ws.cand + ((size_t)tile * kSlots + j) * g.cap;
+    uint32_t answer = 0;
+    if (ok) {      // uniform
+        // the exact keys of the candidates
+        const float* c0 = ws.cand_od + ((size_t)tile * kSlots + j) * 3 * g.cap2;
+        for_each_candidate(&sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
+            const uint32_t k = angle_key(od, v);
+            if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
+        });
+        if (threadIdx.x == 0) {
+            // the prior frame against the exact plane: V = F M; in-plane part Rt (t = Rt th + nu w), tilt nu
+            double m0[3], m1[3];
+            const double v0[3] = {v[0], v[2], v[4]}, v1[3] = {v[1], v[3], v[5]};
+            frame_coordinates(pr, v0, m0);
+            frame_coordinates(pr, v1, m1);
+            const double r00 = m0[0], r01 = m0[1], r10 = m1[0], r11 = m1[1], nu0 = m0[2], nu1 = m1[2];
+            const double det = r00 * r11 - r01 * r10;
+            const double nu = sqrt(nu0 * nu0 + nu1 * nu1);
+            const double stretch = sqrt(r00 * r00 + r01 * r01 + r10 * r10 + r11 * r11);      // >= the largest singular value of Rt
+            bool good = det > 0.9 && stretch < 1.6 && fabs(r01) + fabs(r10) < 0.08 && nu * stretch * 1.05 <= (double)get(&pr->kw) * det;
+            // the boundaries of this slot, mapped: D = Rt d; the answer has to lie strictly between their keys
+            const uint32_t open = get(&pr->open);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double dx = get(&pr->bd[2 * j + e][0]), dy = get(&pr->bd[2 * j + e][1]);
+                const double mx = r00 * dx + r01 * dy, my = r10 * dx + r11 * dy;
+                sh.check[e] = (double)diamond_angle((float)my, (float)mx);
+                if (((open >> (2 * j + e)) & 1u) == 0 && !(my - 0.04 * fabs(mx) > 0.0)) good = false;      // a boundary outside (0, pi)
+            }
+            sh.check[2] = ((open >> (2 * j)) & 1u) ? 1.0 : 0.0;
+            sh.check[3] = ((open >> (2 * j + 1)) & 1u) ? 1.0 : 0.0;
+            sh.ok = good ? 1 : 0;
+        }
+        __syncthreads();
+        ok = sh.ok != 0;
+    }
+    if (stamps) SX_STAMP(st, 10);
+    if (ok) {
+        answer = select_slot_keys(&sh, spill, n, (uint32_t)(rank - below));
+        const float a = key_float(answer);
+        const double slack = 4e-6;
+        if (sh.check[2] == 0.0 && !((double)a >= sh.check[0] + slack)) ok = false;
+        if (sh.check[3] == 0.0 && !((double)a <= sh.check[1] - slack)) ok = false;
+    }
+    if (!ok) {      // the speculation did not hold for this slot (or was never made): every key of the tile, exact and slow
+        __syncthreads();
+        if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << j);
+        reset_scratch(&sh.t);
+        answer = select_whole_group<T>(images, g, tile, j, rank, v, use_all, &sh.t);
+    }
+    if (threadIdx.x == 0) {
+        put(&st.phi_key[j], answer);
+        put(&st.rank[j], rank);
+        put(&st.ncand_seen[j], n_raw);
+    }
+    if (stamps) SX_STAMP(st, 11);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGroupThreads) void conc_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc) {
+    __shared__ SlotScratch sh;
+    const int tile = blockIdx.x >> 1, j = blockIdx.x & 1, slot = 2 + j;
+    GroupState& st = ws.state[tile];
+    const PriorRecord* pr = &ws.prior[tile];
+    const uint32_t spec = get(&st.spec);
+    const int mode = get(&pr->mode);
+    const bool stamps = j == 0;
+    if (stamps) SX_STAMP(st, 12);
+    segment_prefix(&sh, g, ws, tile, slot);
+    if (threadIdx.x == 0) {
+        float vecs[6], he[6], pinv[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vecs[i] = get(&st.vecs[i]);
+        stain_vectors_and_pinv(vecs, get(&st.phi_key[0]), get(&st.phi_key[1]), he, pinv);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            sh.pinv[i] = pinv[i];
+            sh.he[i] = he[i];
+        }
+    }
+    __syncthreads();
+    float pinv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pinv[i] = sh.pinv[i];
+    const unsigned long long n_all = (unsigned long long)g.pixels;
+    const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
+    const uint32_t n = sh.seg_prefix[g.n_seg], n_raw = sh.seg_total;
+    if (stamps) SX_STAMP(st, 13);
+    // every pixel that is not a candidate lies below the answer (that is what gets proved): the answer's rank among the candidates
+    const unsigned long long outside = n_all - (unsigned long long)n;
+    bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !g.spec_fail && sh.seg_overflow == 0 && k99 >= outside && n > 0;
+    uint32_t* spill = ws.cand + ((size_t)tile * kSlots + slot) * g.cap;
+    uint32_t answer = 0;
+    if (ok) {
+        const float* c0 = ws.cand_od + ((size_t)tile * kSlots + slot) * 3 * g.cap2;
+        for_each_candidate(&sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
+            float ca, cb;
+            concentration(od, pinv, ca, cb);
+            const uint32_t k = float_key(j ? cb : ca);
+            if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
+        });
+        if (threadIdx.x == 0) {
+            // row j of the pseudo-inverse in the prior frame: p . x = g0 th0 + g1 th1 + g2 w
+            const double p[3] = {pinv[3 * j], pinv[3 * j + 1], pinv[3 * j + 2]};
+            // p . x = (F^-1 ... ) careful: p . x = p^T F^-T F^T x, so the coordinates are F^-1 applied to ... the TRANSPOSE: solve F^T c = ... see below
+            // With q = F^T x (th0, th1, w) and x = F^-T q:  p . x = (F^-1 p) . q.
+            double gq[3];
+            frame_coordinates(pr, p, gq);
+            const double u1x = get(&pr->cd[2 * j][0]), u1y = get(&pr->cd[2 * j][1]), t1 = get(&pr->cd[2 * j][2]);
+            const double u2x = get(&pr->cd[2 * j + 1][0]), u2y = get(&pr->cd[2 * j + 1][1]), t2 = get(&pr->cd[2 * j + 1][2]);
+            const double det = u1x * u2y - u1y * u2x;
+            bool good = false;
+            double theta = 0.0;
+            if (fabs(det) > 1e-12) {
+                const double alpha = (gq[0] * u2y - gq[1] * u2x) / det, beta = (u1x * gq[1] - u1y * gq[0]) / det;
+                const double l1 = fabs(p[0]) + fabs(p[1]) + fabs(p[2]);
+                good = alpha >= 0.0 && beta >= 0.0 && (alpha + beta) * (double)get(&pr->kw) >= 1.05 * fabs(gq[2]) && (alpha + beta) * (double)get(&pr->kx) >= 3e-6 * l1 && t1 > -1e30 && t2 > -1e30;
+                theta = alpha * t1 + beta * t2;
+            }
+            sh.check[0] = theta;
+            sh.ok = good ? 1 : 0;
+        }
+        __syncthreads();
+        ok = sh.ok != 0;
+    }
+    if (stamps) SX_STAMP(st, 14);
+    if (ok) {
+        answer = select_slot_keys(&sh, spill, n, (uint32_t)(k99 - outside));
+        const double a = (double)key_float(answer), theta = sh.check[0];
+        if (!(a >= theta + 4e-6 * fabs(theta) + 1e-7)) ok = false;
+    }
+    if (!ok) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << slot);
+        reset_scratch(&sh.t);
+        answer = select_whole_group<T>(images, g, tile, slot, k99, pinv, true, &sh.t);
+    }
+    if (threadIdx.x == 0) {
+        const float mc = key_float(answer);
+        put(&st.max_c[j], mc);
+        put(&st.rank[slot], k99);
+        put(&st.ncand_seen[slot], n_raw);
+        StageRecord* rec = &st.rec[2];
+        put(&rec->scale[j], target_max_conc[j] / mc);      // torch_backend.py:452
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                put(&rec->coef[i], pinv[i]);
+                put(&st.pinv[i], pinv[i]);
+                put(&st.he[i], sh.he[i]);
+            }
+        }
+    }
+    if (stamps) SX_STAMP(st, 15);
+}
+
+}  // namespace macenko
+}  // namespace sx
