@@ -99,6 +99,7 @@ struct Geometry {
     int out_code;                 // uint8 input only: SX_BF16 / SX_F16 output (SX_MACENKO_OUT_*), 0 = the reference's output type
     int two_pass;                 // transform: the two-pass form (macenko_twopass.hpp) instead of the four passes of this file
     int prior_units;              // two-pass: 16-pixel sectors the prior stage samples per tile
+    unsigned prior_step_q16;      // two-pass: sectors per sample cell, 16.16 fixed point
     uint32_t cap2;                // two-pass: candidate records per tile and slot
     uint32_t seg_cap;             // two-pass: ... of which every wave of pass A owns this many (its segment)
     int n_seg;                    // two-pass: segments per tile = waves of pass A per tile
@@ -145,6 +146,7 @@ struct Workspace {
     struct PriorRecord* prior;    // two-pass transform: one record per tile
     float* cand_od;               // two-pass transform: [n_tiles][kSlots][3][cap2] optical density of the candidates
     uint32_t* seg_count;          // two-pass transform: [n_tiles][kSlots][n_seg] candidates each wave of pass A produced
+    uint32_t* key_spill;          // two-pass transform: [n_tiles][kSlots][cap2 - kLdsKeys] keys of a slot beyond the stages' LDS array (big tiles)
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -166,11 +168,9 @@ static size_t cand_words(int64_t n_tiles, int64_t pixels) {
 // Two-pass transform: candidate records per tile and slot (the prior keeps ~3 % of the pixels per slot; an overflow is
 // detected and sends the slot to the slow path), and whether a tile size takes that form at all.
 constexpr int kLdsKeys = 16384;        // candidate keys of a slot the stages keep in LDS; the rest spill to the classic candidate area
-constexpr size_t kPriorRecordBytes = 256;
-static uint32_t cap2_for(int64_t pixels) {
-    const int64_t want = std::min<int64_t>(std::max<int64_t>(pixels / 4, 8192), 262144);
-    return (uint32_t)std::min<int64_t>(want, (int64_t)kLdsKeys + (int64_t)cap_for(pixels));
-}
+constexpr size_t kPriorRecordBytes = 384;
+static uint32_t cap2_for(int64_t pixels) { return (uint32_t)std::min<int64_t>(std::max<int64_t>(pixels / 4, 8192), 262144); }
+static size_t key_spill_words(int64_t pixels) { return cap2_for(pixels) > (uint32_t)kLdsKeys ? (size_t)cap2_for(pixels) - kLdsKeys : 0; }      // keys of a slot beyond the stages' LDS array
 static bool two_pass_size(int64_t pixels) { return pixels >= 256 && pixels <= 64ll * kChunk; }      // (at most 256 waves of pass A per tile)
 
 static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
@@ -185,6 +185,7 @@ static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
         total += align_up(kPriorRecordBytes * n, 256);
         total += align_up(sizeof(float) * 3 * kSlots * (size_t)cap2_for(pixels) * n, 256);
         total += align_up(sizeof(uint32_t) * kSlots * 256 * n, 256);
+        total += align_up(sizeof(uint32_t) * kSlots * key_spill_words(pixels) * n, 256);
     }
     return total;
 }
@@ -212,6 +213,8 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     w.cand_od = reinterpret_cast<float*>(p);
     p += align_up(sizeof(float) * 3 * kSlots * (size_t)cap2_for(pixels) * n, 256);
     w.seg_count = reinterpret_cast<uint32_t*>(p);
+    p += align_up(sizeof(uint32_t) * kSlots * 256 * n, 256);
+    w.key_spill = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 
@@ -2338,7 +2341,7 @@ __global__ void export_params_kernel(const GroupState* __restrict__ state, int64
     for (int i = 0; i < 6; ++i) o[10 + i] = st.he[i];
     o[16] = st.max_c[0];
     o[17] = st.max_c[1];
-    o[18] = (float)st.fell_back;
+    o[18] = (float)(st.fell_back | ((st.spec >> 8) << 8));      // (two-pass form: bits 8.. say why a slot left the speculative path, 4 bits per slot)
     for (int s = 0; s < kSlots; ++s) o[19 + s] = (float)st.ncand_seen[s];
     for (int i = 0; i < 9; ++i) o[23 + i] = (float)st.cov[i];
     for (int i = 0; i < 16; ++i) o[32 + i] = (float)((double)(st.stamp[i] - st.stamp[0]) * 0.01);   // us (100 MHz clock)
@@ -2459,6 +2462,7 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
         g.seg_cap = g.cap2 / (uint32_t)g.n_seg;
         const int64_t n_sectors = g.pixels / 16;
         g.prior_units = (int)std::min<int64_t>(std::max<int64_t>(n_sectors / 4, std::min<int64_t>(n_sectors, 64)), kPriorUnitsMax);
+        g.prior_step_q16 = (unsigned)((n_sectors << 16) / g.prior_units);
     }
     // Small batches: with 16384-pixel work items a single 512x512 tile is 16 workgroups on 256 CUs and a bracket pass takes
     // 15 us of pure latency.  The bracket and reconstruct stages (integer counts / independent pixels: the split cannot

@@ -27,7 +27,8 @@
 //   * angles: a linear map with positive determinant keeps the cyclic order of directions, so "th is clockwise of the
 //     boundary d by more than m" implies "t is clockwise of Rt d" as long as m >= |nu||w| + rounding; pass A uses
 //     m = kw |w| + kx |x|_1 and the stage checks |nu| against kw and that the selected key lies strictly between the
-//     mapped boundaries.  Pixels whose angle is not safely inside (0, pi) raise a hazard flag (no wrap-around logic).
+//     mapped boundaries.  That every kept pixel's angle lies safely inside (0, pi) is checked once per tile from the frame
+//     (kept pixels have positive optical densities), not per pixel.
 //   * concentrations: row j of the pseudo-inverse is p = F^-T g; its in-plane part (g0,g1) is a non-negative combination
 //     alpha u1 + beta u2 of the slot's two end directions if it lies in their cone (checked), so for a pixel that
 //     failed both tests (u1.th < T1 - m, u2.th < T2 - m) the exact concentration is below alpha T1 + beta T2 =: Theta;
@@ -43,15 +44,24 @@ constexpr int kPriorUnitsMax = kGroupThreads / 4 * kPriorSweeps;      // sectors
 constexpr int kQueue2 = 512;                          // 16-byte records a wave queues in LDS before it must flush
 constexpr float kSpecSigmas = 5.0f;                   // half-width of a bracket in standard deviations of the sample quantile
 constexpr float kSpecEff = 1.0f;                      // effective (independent) samples per 16-pixel sector
-constexpr float kSpecKw = 0.05f, kSpecKx = 1e-5f;     // margin m = kw |w| + kx |x|_1
+constexpr float kSpecKw = 0.05f, kSpecKx = 1.3e-3f;   // margin m = kw |w| + kx |od|_1 + 1e-6 (kx: the fp16 rounding of the pixel, 2^-10, with room)
 constexpr uint32_t kSpecSlow = 1u, kSpecHazard = 2u;  // GroupState::spec bits
 constexpr int kMaxSegments = 256;                      // waves of pass A per tile (two_pass_size() keeps tiles within 64 work items)
 
+// What pass A tests per pixel is LINEAR in the optical density: nine forms r . od + c (rows of a 16 x 4 matrix).  They run
+// on the matrix core -- one v_mfma_f32_32x32x16_f16 per 64 pixels, see pass_a_item -- with the pixel rounded to fp16 on
+// the way in; the rows themselves are stored as floats that fp16 represents exactly, so pass A and the proofs of the
+// stages talk about the same numbers, and the input rounding (< 2^-10 relative, round-toward-zero) is part of the margin kx.
+//   row 0 / 1   cross(d, th) for the lower / upper boundary d of angle slot 0 (zero row: that side is open)
+//   row 2 / 3   the same for angle slot 1
+//   row 4 / 5   u . th - T at the two end directions of concentration slot 0;   row 6 / 7   slot 1
+//   row 8       w = an . od (the out-of-plane coordinate, for the margin)
+constexpr int kRowBelowA = 0, kRowAboveA = 1, kRowBelowB = 2, kRowAboveB = 3, kRowConc = 4, kRowW = 8;
 struct alignas(128) PriorRecord {
     float a0[3], a1[3], an[3];     // prior frame: th0 = a0.x, th1 = a1.x, w = an.x
-    float bd[4][3];                // angle boundaries (dx, dy, 0): lower / upper of slot 0, lower / upper of slot 1; (0, 0) = open side
-    float cd[4][3];                // concentration tests (ux, uy, T): [2 * slot + end]
-    float kw, kx;
+    float rows[16][4];             // (r0, r1, r2, c): the form's value is r . od + c
+    float kw, kx;                  // margin m = kw |w| + kx |od|_1 + 1e-6
+    float cmax[4];                 // largest sample value of u . th per concentration row (the stages size their histogram bins with it)
     int32_t mode;                  // 0: speculate, 1: slow (the stages select over the whole tile)
     int32_t min_first;
     uint32_t open;                 // bit i: angle boundary i is open (nothing is excluded on that side)
@@ -66,12 +76,15 @@ struct alignas(16) PriorScratch {
     float frame[9];
     float bdir[4][2];
     float cthr[4];
+    uint32_t cmax[4];
     uint32_t open;
 };
 
-// One wave: the bin of a kPriorBins-bin histogram that holds 0-based rank `rank` (kPriorBins / 64 bins per lane).
+// One wave: the bin of a kPriorBins-bin histogram that holds 0-based rank `rank`: kPriorBins / 64 consecutive bins per lane,
+// then the owner lane's bins one per lane.
 __device__ __forceinline__ uint32_t prior_pick_bin(const uint32_t* hist, uint32_t rank) {
     constexpr int kPer = kPriorBins / kWave;
+    static_assert(kPer <= kWave, "second level: one bin per lane");
     const int lane = (int)lane_id();
     uint32_t mine = 0;
 #pragma unroll 8
@@ -79,15 +92,23 @@ __device__ __forceinline__ uint32_t prior_pick_bin(const uint32_t* hist, uint32_
     const uint32_t incl = wave_scan_u32(mine);
     const uint64_t over = __ballot(incl > rank);
     const int owner = over ? (__ffsll((long long)over) - 1) : (kWave - 1);
-    uint32_t r = rank - (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), owner);
-    uint32_t bin = kPer * owner;
-    for (int i = 0; i < kPer - 1; ++i) {      // (uniform: every lane walks the owner's bins)
-        const uint32_t h = hist[kPer * owner + i];
-        if (r < h) break;
-        r -= h;
-        ++bin;
-    }
-    return bin;
+    const uint32_t r = rank - (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), owner);
+    const uint32_t h = lane < kPer ? hist[kPer * owner + lane] : 0u;
+    const uint32_t incl2 = wave_scan_u32(h);
+    const uint64_t over2 = __ballot(lane < kPer && incl2 > r);
+    const int sub = over2 ? (__ffsll((long long)over2) - 1) : (kPer - 1);
+    return (uint32_t)(kPer * owner + sub);
+}
+
+__device__ __forceinline__ float wave_total_f32(float x) {      // fixed order; the total in lane 63 only
+    auto step = [](float v, auto mover) { return v + __uint_as_float(mover(__float_as_uint(v))); };
+    x = step(x, [](uint32_t b) { return dpp_move<0x111, 0xF>(0u, b); });
+    x = step(x, [](uint32_t b) { return dpp_move<0x112, 0xF>(0u, b); });
+    x = step(x, [](uint32_t b) { return dpp_move<0x114, 0xF>(0u, b); });
+    x = step(x, [](uint32_t b) { return dpp_move<0x118, 0xF>(0u, b); });
+    x = step(x, [](uint32_t b) { return dpp_move<0x142, 0xA>(0u, b); });
+    x = step(x, [](uint32_t b) { return dpp_move<0x143, 0xC>(0u, b); });
+    return x;
 }
 
 // The presample: unit u is one sector (16 consecutive pixels) of cell u at a hashed offset; four lanes per sector, so a
@@ -102,10 +123,11 @@ __device__ __forceinline__ bool prior_load(const T* __restrict__ img, const Geom
 #pragma unroll
         for (int i = 0; i < 4; ++i) u[c][i] = 0.0f;
     if (have) {
-        const int64_t n_sectors = g.pixels / 16;
-        const int64_t start = (int64_t)unit * n_sectors / g.prior_units, width = (int64_t)(unit + 1) * n_sectors / g.prior_units - start;
-        const int64_t sector = start + (int64_t)((((uint32_t)unit * 0x9E3779B1u) >> 8) % (uint32_t)width);
-        const int64_t p = (sector * 4 + (tid & 3)) * 4;
+        // cell u = sectors [u step, (u + 1) step) in 16.16 fixed point (no integer divisions here: they cost the two looks ~2 us each)
+        const uint64_t step = (uint64_t)g.prior_step_q16;
+        const uint32_t start = (uint32_t)(((uint64_t)unit * step) >> 16), width = (uint32_t)(((uint64_t)(unit + 1) * step) >> 16) - start;
+        const uint32_t sector = start + (((((uint32_t)unit * 0x9E3779B1u) >> 16) * width) >> 16);
+        const int64_t p = ((int64_t)sector * 4 + (tid & 3)) * 4;
         if constexpr (kVec) {
             load_pixels<T, 4, kInter>(img, g.pixels, p, u);
         } else {
@@ -143,6 +165,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         put(&st.fell_back, 0u);
         put(&st.spec, 0u);
         sh.n_kept = sh.n_all = sh.hazard = sh.open = sh.r_max = 0;
+        sh.cmax[0] = sh.cmax[1] = sh.cmax[2] = sh.cmax[3] = 0;
     }
     for (int i = tid; i < 4 * kPriorBins; i += kGroupThreads) (&sh.hist[0][0])[i] = 0;
 
@@ -174,10 +197,11 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
             }
         }
         SX_STAMP(st, 1);
+        // (fp32 across the wave: a prior needs no more; the sixteen waves and the covariance are fp64)
 #pragma unroll
         for (int k = 0; k < kPartial; ++k) {
-            const double s = wave_total_f64((double)m[k]);
-            if (lane == kWave - 1) sh.red[wave][k] = s;
+            const float s = wave_total_f32(m[k]);
+            if (lane == kWave - 1) sh.red[wave][k] = (double)s;
         }
     }
     __syncthreads();
@@ -213,7 +237,13 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
             put(&st.spec, kSpecSlow);
         }
     };
-    if (m_kept < 3 || g.pixels < 16) {
+    // Kept pixels have every od_c >= 0.15 > 0, so th1 >= min(a1) |od|_1, |th0| <= max|a0| |od|_1, |w| <= max|an| |od|_1: if the
+    // largest-eigenvalue vector is positive enough, every kept pixel's angle lies safely inside (0, pi) and pass A needs no
+    // wrap-around test per pixel (real H&E: a1 ~ (0.5, 0.7, 0.5)).
+    const float a1_min = fminf(sh.frame[3], fminf(sh.frame[4], sh.frame[5]));
+    const float a0_max = fmaxf(fabsf(sh.frame[0]), fmaxf(fabsf(sh.frame[1]), fabsf(sh.frame[2])));
+    const float an_max = fmaxf(fabsf(sh.frame[6]), fmaxf(fabsf(sh.frame[7]), fabsf(sh.frame[8])));
+    if (m_kept < 3 || g.pixels < 16 || !(a1_min > 0.06f * a0_max + 2.0f * kSpecKw * an_max + 0.01f)) {
         give_up();
         return;
     }
@@ -329,13 +359,18 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
     for (int i = tid; i < kPriorBins; i += kGroupThreads) sh.hist[0][i] = 0;      // (the angle histogram has been read)
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q) {
+        float k_max = 0.0f;
 #pragma unroll
         for (int s = 0; s < kPriorSweeps; ++s)
             if ((have_bits >> s) & 1u) {
                 const float k = fmaf(cu[q][0], t0[s][s], cu[q][1] * t1[s][s]);
+                k_max = fmaxf(k_max, k);
                 atomicAdd(&sh.hist[q][min((uint32_t)fmaxf(k * c_scale, 0.0f), (uint32_t)(kPriorBins - 1))], 1u);
             }
+        const uint32_t km = wave_max_u32(__float_as_uint(k_max));
+        if (lane == 0) atomicMax(&sh.cmax[q], km);
+    }
     __syncthreads();
     SX_STAMP(st, 6);
     if (wave < 4) {
@@ -346,6 +381,34 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         if (lane == 0) sh.cthr[wave] = (level > 0.0f && b > 0) ? (float)b * (r_max / (float)kPriorBins) : -__builtin_huge_valf();      // the bin's lower edge
     }
     __syncthreads();
+    if (tid < 9) {      // one test row per thread (compile-time indices: a run-time index would send bd / cu to scratch memory)
+        const float* a0 = &sh.frame[0];
+        const float* a1 = &sh.frame[3];
+        const float* an = &sh.frame[6];
+        const uint32_t open = sh.open;
+        float row[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (tid == q && ((open >> q) & 1u) == 0) {      // cross(d, th) = dx th1 - dy th0; an open side keeps the zero row
+#pragma unroll
+                for (int c = 0; c < 3; ++c) row[c] = bd[q][0] * a1[c] - bd[q][1] * a0[c];
+            }
+            if (tid == kRowConc + q) {                       // u . th - T
+#pragma unroll
+                for (int c = 0; c < 3; ++c) row[c] = cu[q][0] * a0[c] + cu[q][1] * a1[c];
+                row[3] = sh.cthr[q] > -1e30f ? -sh.cthr[q] : 60000.0f;      // no threshold: every pixel is a candidate
+            }
+        }
+        if (tid == kRowW) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) row[c] = an[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) put(&pr->rows[tid][c], __half2float(__float2half_rn(row[c])));
+    } else if (tid < 16) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) put(&pr->rows[tid][c], 0.0f);
+    }
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -353,22 +416,13 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
             put(&pr->a1[i], sh.frame[3 + i]);
             put(&pr->an[i], sh.frame[6 + i]);
         }
-        const uint32_t open = sh.open;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool is_open = ((open >> q) & 1u) != 0;      // the zero direction: pass A excludes nothing on that side
-            put(&pr->bd[q][0], is_open ? 0.0f : bd[q][0]);
-            put(&pr->bd[q][1], is_open ? 0.0f : bd[q][1]);
-            put(&pr->bd[q][2], 0.0f);
-            put(&pr->cd[q][0], cu[q][0]);
-            put(&pr->cd[q][1], cu[q][1]);
-            put(&pr->cd[q][2], sh.cthr[q]);
-        }
         put(&pr->kw, kSpecKw);
         put(&pr->kx, kSpecKx);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) put(&pr->cmax[q], __uint_as_float(sh.cmax[q]));
         put(&pr->mode, 0);
         put(&pr->min_first, min_first ? 1 : 0);
-        put(&pr->open, open);
+        put(&pr->open, sh.open);
     }
     SX_STAMP(st, 7);
 }
@@ -379,7 +433,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
 template <int TPB> struct PassAScratch {
     StatsScratch<TPB> stats;
     uint4 queue[TPB / kWave][kQueue2];
-    uint32_t below[2], hazard;
+    uint32_t below[2];
 };
 
 // Moves the records a wave queued to its own SEGMENT of the tile's per-slot candidate arrays (record i goes to slot s iff
@@ -419,24 +473,23 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
     const PriorRecord* __restrict__ pr = &ws.prior[tile];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const bool speculate = get(&pr->mode) == 0;
-    // the prior record: uniform values (scalar registers)
-    float a0[3], a1[3], an[3], bd[4][3], cd[4][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        a0[i] = get(&pr->a0[i]);
-        a1[i] = get(&pr->a1[i]);
-        an[i] = get(&pr->an[i]);
+    // The A operand of the tests' MFMA (see below): lane l holds A[row r = l & 31][k = 8 (l >> 5) + j], j = 0..7.  Output row
+    // R = 8 a + 4 H + c carries test 4 a + c of the pixel in lane half H, so row R reads the pixel data of k-block H only.
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    typedef float float16v __attribute__((ext_vector_type(16)));
+    half8 test_rows;
+    {
+        const uint32_t l = lane_id(), r = l & 31u, h = l >> 5, row_half = (r >> 2) & 1u, test = (r & 3u) + 4u * (r >> 3);
+        const float4 coef = *reinterpret_cast<const float4*>(&pr->rows[test][0]);
+        const bool mine = h == row_half;
+        test_rows[0] = (_Float16)(mine ? coef.x : 0.0f);
+        test_rows[1] = (_Float16)(mine ? coef.y : 0.0f);
+        test_rows[2] = (_Float16)(mine ? coef.z : 0.0f);
+        test_rows[3] = (_Float16)(mine ? coef.w : 0.0f);
+        test_rows[4] = test_rows[5] = test_rows[6] = test_rows[7] = (_Float16)0.0f;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            bd[q][i] = get(&pr->bd[q][i]);
-            cd[q][i] = get(&pr->cd[q][i]);
-        }
     const float kw = get(&pr->kw), kx = get(&pr->kx);
     if (threadIdx.x < 2) sh->below[threadIdx.x] = 0;
-    if (threadIdx.x == 0) sh->hazard = 0;
 
     constexpr int kShortRun = 32 / V > 0 ? 32 / V : 1;      // packs per fp32 run -- the grouping of stats_item, bit for bit
     double acc[kPartial];
@@ -448,7 +501,6 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
 
     uint4* queue = sh->queue[wave];
     uint32_t n_q = 0, have[kSlots] = {0u, 0u, 0u, 0u}, below_a = 0, below_b = 0;
-    uint64_t hazard = 0;
     float* cand_tile = ws.cand_od + (size_t)tile * kSlots * 3 * g.cap2;
     const uint32_t seg = (uint32_t)chunk_id * (TPB / kWave) + (uint32_t)wave, seg_base = seg * g.seg_cap;
     auto flush = [&]() {
@@ -466,76 +518,103 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
     __syncthreads();      // the scratch words above
 
     int in_run = 0;
-    for (int64_t base_p = p_begin; base_p < p_end; base_p += (int64_t)TPB * V) {
-        const bool live = base_p + mine < p_end;
-        float u[3][V];
+    // (the loop exists twice, with and without the speculation: a run-time test per pixel is a branch per pixel)
+    auto sweep = [&](auto with_tests) {
+        constexpr bool kTests = decltype(with_tests)::value;
+        constexpr int G = 1;      // pixels whose MFMAs are in flight together (measured: two together 48.3 us against 46.5 -- 16 more accumulator registers, and the other waves of the SIMD cover one MFMA's latency anyway)
+        for (int64_t base_p = p_begin; base_p < p_end; base_p += (int64_t)TPB * V) {
+            const bool live = base_p + mine < p_end;
+            float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int i = 0; i < V; ++i) u[c][i] = next[c][i];
-        const int64_t p_next = base_p + (int64_t)TPB * V + mine;
-        if (p_next < p_end) load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p_next, next);
-        const uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
+                for (int i = 0; i < V; ++i) u[c][i] = next[c][i];
+            const int64_t p_next = base_p + (int64_t)TPB * V + mine;
+            if (p_next < p_end) load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p_next, next);
+            const uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            float od[3];
+            for (int i0 = 0; i0 < V; i0 += G) {
+                float od[G][3];
+                bool kept[G];
+                float16v forms[G];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u[c][i], tb);
-            const bool kept = live && od_selected(od, false);
-            if (kept) {      // (stats_item multiplies by a 0 / 1 `keep` instead: the same bits, four instructions more)
-                m[0] += 1.0f;
-                m[1] += od[0];
-                m[2] += od[1];
-                m[3] += od[2];
-                m[4] = fmaf(od[0], od[0], m[4]);
-                m[5] = fmaf(od[0], od[1], m[5]);
-                m[6] = fmaf(od[0], od[2], m[6]);
-                m[7] = fmaf(od[1], od[1], m[7]);
-                m[8] = fmaf(od[1], od[2], m[8]);
-                m[9] = fmaf(od[2], od[2], m[9]);
-            }
-            if (speculate) {
-                const float t0 = fmaf(od[2], a0[2], fmaf(od[1], a0[1], od[0] * a0[0]));
-                const float t1 = fmaf(od[2], a1[2], fmaf(od[1], a1[1], od[0] * a1[0]));
-                const float w = fmaf(od[2], an[2], fmaf(od[1], an[1], od[0] * an[0]));
-                const float mrg = fmaf(kw, fabsf(w), kx * (fabsf(od[0]) + fabsf(od[1]) + fabsf(od[2])));
-                const uint64_t valid = __builtin_amdgcn_ballot_w64(kept);
-                // angle slots: cross(d, th) = dx th1 - dy th0 > 0 iff th is counter-clockwise of d (a larger angle); "below" is
-                // cross < -m, "above" cross > m, the margin folded into the multiply-adds; an open side has d = 0: never true
-                const uint64_t lt_a = __builtin_amdgcn_ballot_w64(fmaf(bd[0][0], t1, fmaf(-bd[0][1], t0, mrg)) < 0.0f);
-                const uint64_t gt_a = __builtin_amdgcn_ballot_w64(fmaf(bd[1][0], t1, fmaf(-bd[1][1], t0, -mrg)) > 0.0f);
-                const uint64_t lt_b = __builtin_amdgcn_ballot_w64(fmaf(bd[2][0], t1, fmaf(-bd[2][1], t0, mrg)) < 0.0f);
-                const uint64_t gt_b = __builtin_amdgcn_ballot_w64(fmaf(bd[3][0], t1, fmaf(-bd[3][1], t0, -mrg)) > 0.0f);
-                hazard |= valid & ~__builtin_amdgcn_ballot_w64(fmaf(-0.05f, fabsf(t0), t1) > mrg);
-                below_a += (uint32_t)__popcll(valid & lt_a);
-                below_b += (uint32_t)__popcll(valid & lt_b);
-                const uint64_t c_a = valid & ~lt_a & ~gt_a, c_b = valid & ~lt_b & ~gt_b;
-                // concentration slots: every pixel takes part; a candidate passes the threshold at either end direction
-                const uint64_t c_c = live_mask & (__builtin_amdgcn_ballot_w64(fmaf(cd[0][0], t0, fmaf(cd[0][1], t1, mrg)) >= cd[0][2]) |
-                                                  __builtin_amdgcn_ballot_w64(fmaf(cd[1][0], t0, fmaf(cd[1][1], t1, mrg)) >= cd[1][2]));
-                const uint64_t c_d = live_mask & (__builtin_amdgcn_ballot_w64(fmaf(cd[2][0], t0, fmaf(cd[2][1], t1, mrg)) >= cd[2][2]) |
-                                                  __builtin_amdgcn_ballot_w64(fmaf(cd[3][0], t0, fmaf(cd[3][1], t1, mrg)) >= cd[3][2]));
-                const uint64_t any = c_a | c_b | c_c | c_d;
-                if (any) {      // wave-uniform
-                    uint32_t flags = __builtin_amdgcn_inverse_ballot_w64(c_a) ? 1u : 0u;
-                    flags |= __builtin_amdgcn_inverse_ballot_w64(c_b) ? 2u : 0u;
-                    flags |= __builtin_amdgcn_inverse_ballot_w64(c_c) ? 4u : 0u;
-                    flags |= __builtin_amdgcn_inverse_ballot_w64(c_d) ? 8u : 0u;
-                    if (__builtin_amdgcn_inverse_ballot_w64(any)) queue[n_q + rank_in_mask(any)] = make_uint4(__float_as_uint(od[0]), __float_as_uint(od[1]), __float_as_uint(od[2]), flags);
-                    n_q += (uint32_t)__popcll(any);
+                for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) od[gi][c] = od_of<T>(u[c][i0 + gi], tb);
+                    kept[gi] = live && od_selected(od[gi], false);
+                    if (kept[gi]) {      // (stats_item multiplies by a 0 / 1 `keep` instead: the same bits, four instructions more)
+                        const float* o = od[gi];
+                        m[0] += 1.0f;
+                        m[1] += o[0];
+                        m[2] += o[1];
+                        m[3] += o[2];
+                        m[4] = fmaf(o[0], o[0], m[4]);
+                        m[5] = fmaf(o[0], o[1], m[5]);
+                        m[6] = fmaf(o[0], o[2], m[6]);
+                        m[7] = fmaf(o[1], o[1], m[7]);
+                        m[8] = fmaf(o[1], o[2], m[8]);
+                        m[9] = fmaf(o[2], o[2], m[9]);
+                    }
+                    if constexpr (kTests) {
+                        // Nine linear forms of the pixel on the matrix core: B[k = 8 h + j][col = l & 31] is the lane's own pixel
+                        // (od0, od1, od2, 1, 0, 0, 0, 0) in fp16, so column c of the product mixes the pixels of lanes c (k-block 0)
+                        // and c + 32 (k-block 1), and the rows sort them apart again (test_rows): forms[i] of EVERY lane is form i
+                        // of its own pixel -- C/D layout: col = l & 31, row = (i & 3) + 8 (i >> 2) + 4 (l >> 5).  One instruction (32
+                        // cycles of a pipe that is otherwise idle) instead of ~27 multiply-adds per pixel on the vector ALU, which
+                        // is what bounds this pass.
+                        typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+                        typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+                        const fp16x2 p01 = __builtin_amdgcn_cvt_pkrtz(od[gi][0], od[gi][1]), p2c = __builtin_amdgcn_cvt_pkrtz(od[gi][2], 1.0f);
+                        uint4v packed;
+                        packed[0] = __builtin_bit_cast(uint32_t, p01);
+                        packed[1] = __builtin_bit_cast(uint32_t, p2c);
+                        packed[2] = packed[3] = 0u;
+                        float16v zero;
+#pragma unroll
+                        for (int z = 0; z < 16; ++z) zero[z] = 0.0f;
+                        forms[gi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(test_rows, __builtin_bit_cast(half8, packed), zero, 0, 0, 0);
+                    }
                 }
-                if (__builtin_expect(n_q > (uint32_t)(kQueue2 - kWave), 0)) flush();      // the next pixel adds at most 64 records
-            }
-        }
-        if (++in_run == kShortRun) {
+                if constexpr (kTests) {
 #pragma unroll
-            for (int k = 0; k < kPartial; ++k) {
-                acc[k] += (double)m[k];
-                m[k] = 0.0f;
+                    for (int gi = 0; gi < G; ++gi) {
+                        const float* o = od[gi];
+                        const float16v& f = forms[gi];
+                        const float mrg = fmaf(kw, fabsf(f[kRowW]), fmaf(kx, fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]), 1e-6f));
+                        const uint64_t valid = __builtin_amdgcn_ballot_w64(kept[gi]);
+                        // angle slots: "below" is cross(d, th) < -m, "above" cross(d, th) > m; an open side has the zero row: never true
+                        const uint64_t lt_a = __builtin_amdgcn_ballot_w64(f[kRowBelowA] < -mrg), gt_a = __builtin_amdgcn_ballot_w64(f[kRowAboveA] > mrg);
+                        const uint64_t lt_b = __builtin_amdgcn_ballot_w64(f[kRowBelowB] < -mrg), gt_b = __builtin_amdgcn_ballot_w64(f[kRowAboveB] > mrg);
+                        below_a += (uint32_t)__popcll(valid & lt_a);
+                        below_b += (uint32_t)__popcll(valid & lt_b);
+                        const uint64_t c_a = valid & ~lt_a & ~gt_a, c_b = valid & ~lt_b & ~gt_b;
+                        // concentration slots: every pixel takes part; a candidate reaches the threshold at either end direction
+                        const uint64_t c_c = live_mask & (__builtin_amdgcn_ballot_w64(f[kRowConc] >= -mrg) | __builtin_amdgcn_ballot_w64(f[kRowConc + 1] >= -mrg));
+                        const uint64_t c_d = live_mask & (__builtin_amdgcn_ballot_w64(f[kRowConc + 2] >= -mrg) | __builtin_amdgcn_ballot_w64(f[kRowConc + 3] >= -mrg));
+                        const uint64_t any = c_a | c_b | c_c | c_d;
+                        if (any) {      // wave-uniform
+                            uint32_t flags = __builtin_amdgcn_inverse_ballot_w64(c_a) ? 1u : 0u;
+                            flags |= __builtin_amdgcn_inverse_ballot_w64(c_b) ? 2u : 0u;
+                            flags |= __builtin_amdgcn_inverse_ballot_w64(c_c) ? 4u : 0u;
+                            flags |= __builtin_amdgcn_inverse_ballot_w64(c_d) ? 8u : 0u;
+                            if (__builtin_amdgcn_inverse_ballot_w64(any)) queue[n_q + rank_in_mask(any)] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), flags);
+                            n_q += (uint32_t)__popcll(any);
+                        }
+                        if (__builtin_expect(n_q > (uint32_t)(kQueue2 - kWave), 0)) flush();      // the next pixel adds at most 64 records
+                    }
+                }
             }
-            in_run = 0;
+            if (++in_run == kShortRun) {
+#pragma unroll
+                for (int k = 0; k < kPartial; ++k) {
+                    acc[k] += (double)m[k];
+                    m[k] = 0.0f;
+                }
+                in_run = 0;
+            }
         }
-    }
+    };
+    if (speculate) sweep(std::true_type{}); else sweep(std::false_type{});
     if (in_run) {
 #pragma unroll
         for (int k = 0; k < kPartial; ++k) acc[k] += (double)m[k];
@@ -556,7 +635,6 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
             for (int s = 0; s < kSlots; ++s) put(&counts[(size_t)s * g.n_seg], have[s]);
             if (below_a) atomicAdd(&sh->below[0], below_a);
             if (below_b) atomicAdd(&sh->below[1], below_b);
-            if (hazard) atomicOr(&sh->hazard, 1u);
         }
     }
     __syncthreads();
@@ -569,7 +647,6 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
     if (speculate && threadIdx.x == kPartial) {      // (no value comes back: nothing waits for these)
         if (sh->below[0]) atomicAdd(&st.below[0], sh->below[0]);
         if (sh->below[1]) atomicAdd(&st.below[1], sh->below[1]);
-        if (sh->hazard) atomicOr(&st.spec, kSpecHazard);
     }
     double kept_total = 0.0;
 #pragma unroll
@@ -594,7 +671,7 @@ struct alignas(16) SlotScratch {
     uint32_t keys[kLdsKeys];
     float vecs[6], pinv[6], he[6];
     double check[8];
-    uint32_t lo, hi, n_list, bin, rank_in_bin, result;
+    uint32_t lo, hi, n_list, bin, rank_in_bin, result, range_first, range_last, bin_count;
     int ok, use_all;
     unsigned long long n_sel;
     uint32_t seg_prefix[kMaxSegments + 1], seg_total, seg_overflow;
@@ -632,17 +709,39 @@ __device__ __forceinline__ void segment_prefix(SlotScratch* sh, const Geometry& 
         }
     }
 }
-// Every candidate of the slot once: a team of blockDim / n_seg consecutive threads per segment, four loads per plane in flight
-// per thread (a plain one-record-per-iteration loop pays one memory latency per record: 7-9 us per stage).  fn(i, od): i is
-// the candidate's index in the slot (segments in order), od its optical density.
-template <class Fn>
-__device__ __forceinline__ void for_each_candidate(const SlotScratch* sh, const Geometry& g, const float* __restrict__ c0, Fn fn) {
+// Every candidate of the slot once: a team of blockDim / n_seg consecutive threads per segment.  The first kPre records of a
+// thread are requested at the TOP of the kernel, before the segment fills are known (entries beyond a fill are in-bounds
+// garbage that is never used), so the stage pays one memory round trip for counters, moments and candidates together; a
+// plain one-record-per-iteration loop paid one per record (7-9 us per stage).  fn(i, od): i is the candidate's index in the
+// slot (segments in order), od its optical density.
+template <int kPre> struct CandPrefetch {
+    float od[kPre][3];
+};
+template <int kPre>
+__device__ __forceinline__ void prefetch_candidates(CandPrefetch<kPre>& pf, const Geometry& g, const float* __restrict__ c0) {
+    const uint32_t team = blockDim.x / (uint32_t)g.n_seg, k = threadIdx.x / team, r = threadIdx.x - k * team;
+    const float* src = c0 + (size_t)k * g.seg_cap;
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const uint32_t o = r + u * team;
+        const bool in = k < (uint32_t)g.n_seg && o < g.seg_cap;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pf.od[u][c] = in ? get(&src[(size_t)c * g.cap2 + o]) : 0.0f;
+    }
+}
+template <int kPre, class Fn>
+__device__ __forceinline__ void for_each_candidate(const CandPrefetch<kPre>& pf, const SlotScratch* sh, const Geometry& g, const float* __restrict__ c0, Fn fn) {
     const uint32_t team = blockDim.x / (uint32_t)g.n_seg, k = threadIdx.x / team, r = threadIdx.x - k * team;
     if (k >= (uint32_t)g.n_seg) return;
     const uint32_t first = sh->seg_prefix[k], cnt = sh->seg_prefix[k + 1] - first;
     const float* src = c0 + (size_t)k * g.seg_cap;
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const uint32_t o = r + u * team;
+        if (o < cnt) fn(first + o, pf.od[u]);
+    }
     constexpr int kFlight = 4;
-    for (uint32_t off = r; off < cnt; off += team * kFlight) {
+    for (uint32_t off = r + kPre * team; off < cnt; off += team * kFlight) {
         float od[kFlight][3];
 #pragma unroll
         for (int u = 0; u < kFlight; ++u) {
@@ -660,78 +759,111 @@ __device__ __forceinline__ void for_each_candidate(const SlotScratch* sh, const 
 
 __device__ __forceinline__ uint32_t slot_key(const SlotScratch* sh, const uint32_t* __restrict__ spill, uint32_t i) { return i < (uint32_t)kLdsKeys ? sh->keys[i] : get(&spill[i - kLdsKeys]); }
 
-// exact element of 0-based rank `rank` among the n keys of the slot (n >= 1, rank < n); whole workgroup, uniform result
-__device__ uint32_t select_slot_keys(SlotScratch* sh, const uint32_t* __restrict__ spill, uint32_t n, uint32_t rank) {
-    const uint32_t lane = lane_id();
-    const int wave = threadIdx.x / kWave;
+// The selection's scratch words; call before the keys are produced (a barrier must lie between this and select_slot_keys).
+__device__ __forceinline__ void select_prepare(SlotScratch* sh) {
     if (threadIdx.x == 0) {
         sh->lo = 0xFFFFFFFFu;
         sh->hi = 0u;
         sh->n_list = 0;
         sh->result = 0;
     }
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) sh->t.hist_c[0][i] = 0;
-    __syncthreads();
-    {
-        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t k = slot_key(sh, spill, i);
-            mn = min(mn, k);
-            mx = max(mx, k);
-        }
-        mn = wave_min_u32(mn);
-        mx = wave_max_u32(mx);
-        if (lane == 0 && mn != 0xFFFFFFFFu) {
-            atomicMin(&sh->lo, mn);
-            atomicMax(&sh->hi, mx);
-        }
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) (&sh->t.hist_c[0][0])[i] = 0;
+}
+// The range of the keys a thread produced (the phase that makes the keys also finds their range: one sweep less)
+__device__ __forceinline__ void publish_range(SlotScratch* sh, uint32_t mn, uint32_t mx) {
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    if (lane_id() == 0 && mn != 0xFFFFFFFFu) {
+        atomicMin(&sh->lo, mn);
+        atomicMax(&sh->hi, mx);
     }
-    __syncthreads();
-    const double origin = bin_origin_for(sh->lo), scale = bin_scale_for(sh->lo, sh->hi);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&sh->t.hist_c[0][bin_of(slot_key(sh, spill, i), origin, scale)], 1u);
-    __syncthreads();
-    if (wave == 0) {
-        uint32_t b, rb;
-        scan_pick32(sh->t.hist_c[0], rank, b, rb);
-        if (lane == 0) {
-            sh->bin = b;
-            sh->rank_in_bin = rb;
+}
+
+// exact element of 0-based rank `rank` among the n keys of the slot (n >= 1, rank < n); whole workgroup, uniform result.
+// select_prepare() and publish_range() of every key come first, then a barrier.  A thread sweeps a CONTIGUOUS share of the
+// keys, so the lanes of a wave touch candidates far apart in the tile: neighbours in the arrays are neighbours in the image,
+// with nearly the same key -- the same histogram bin, and LDS atomics on one bin take their turns.
+// Two levels of 256 value-linear bins: over the keys' range, then -- only when the picked bin holds more keys than the short
+// list -- over that bin's own key range.  Tiles from 8-bit data tie heavily (the same colour, the same key): a bin there
+// holds thousands of keys of a handful of values, which the second level separates or recognises as one value.
+__device__ uint32_t select_slot_keys(SlotScratch* sh, const uint32_t* __restrict__ spill, uint32_t n, uint32_t rank, bool level0_filled, unsigned long long* dbg = nullptr) {
+    const uint32_t lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    const uint32_t share = (n + blockDim.x - 1) / blockDim.x, i_begin = min(threadIdx.x * share, n), i_end = min(i_begin + share, n);
+    double origin = bin_origin_for(sh->lo), scale = bin_scale_for(sh->lo, sh->hi);      // (lo, hi: the keys' range, or the range the caller binned them over)
+    uint32_t k_first = 0u, k_last = 0xFFFFFFFFu, want = rank;      // the keys still in play: k_first <= key <= k_last
+    uint32_t* hist = sh->t.hist_c[0];
+    for (int level = 0; level < 2; ++level) {
+        if (level > 0 || !level0_filled) {
+            for (uint32_t i = i_begin; i < i_end; ++i) {
+                const uint32_t k = slot_key(sh, spill, i);
+                if (k >= k_first && k <= k_last) atomicAdd(&hist[bin_of(k, origin, scale)], 1u);
+            }
+            __syncthreads();
         }
+        if (dbg && threadIdx.x == 0) dbg[level] = (unsigned long long)wall_clock64();
+        if (wave == 0) {
+            uint32_t b, rb;
+            scan_pick32(hist, want, b, rb);
+            if (lane == 0) {
+                uint32_t first, last;
+                bin_key_range(b, origin, scale, first, last);
+                sh->bin = b;
+                sh->rank_in_bin = rb;
+                sh->range_first = max(first, k_first);
+                sh->range_last = min(last, k_last);
+                sh->bin_count = hist[b];
+            }
+        }
+        __syncthreads();
+        k_first = sh->range_first;
+        k_last = sh->range_last;
+        want = sh->rank_in_bin;
+        const uint32_t in_bin = sh->bin_count;
+        if (in_bin <= (uint32_t)kShortList || level == 1) break;      // uniform
+        // (tighten to the keys actually present in the bin?  not needed: the bin's own range is already 1/256 of the first)
+        if (k_first == k_last) return k_first;                      // one key value fills the bin
+        hist = sh->t.hist_c[1];      // zeroed by select_prepare
+        origin = bin_origin_for(k_first);
+        scale = bin_scale_for(k_first, k_last);
     }
-    __syncthreads();
-    const uint32_t b = sh->bin;
+    if (k_first == k_last) return k_first;
+    // the keys of the picked bin (at most the short list's worth, ties aside), listed and ranked by counting
     uint32_t* list = &sh->t.keys[0][0];      // 2 * kSample entries
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (uint32_t i = i_begin; i < i_end; ++i) {
         const uint32_t k = slot_key(sh, spill, i);
-        if (bin_of(k, origin, scale) == b) {
+        if (k >= k_first && k <= k_last) {
             const uint32_t at = atomicAdd(&sh->n_list, 1u);
             if (at < (uint32_t)(2 * kSample)) list[at] = k;
         }
     }
     __syncthreads();
-    const uint32_t n_list = sh->n_list, want = sh->rank_in_bin;
+    if (dbg && threadIdx.x == 0) dbg[2] = (unsigned long long)wall_clock64();
+    const uint32_t n_list = sh->n_list;
     if (__builtin_expect(n_list <= (uint32_t)kShortList, 1)) {
         rank_pick(list, n_list, want, threadIdx.x, blockDim.x, &sh->result);
         __syncthreads();
         return sh->result;
     }
     if (n_list <= (uint32_t)(2 * kSample)) return radix_select_stream((unsigned long long)n_list, (unsigned long long)want, [list](unsigned long long i, uint32_t& k) { k = list[i]; return true; }, &sh->t);
-    // a bin with more keys than the list holds (heavy ties): radix rounds over all the keys
+    // more keys than the list holds: radix rounds over all the keys
     return radix_select_stream((unsigned long long)n, (unsigned long long)rank, [sh, spill](unsigned long long i, uint32_t& k) { k = slot_key(sh, spill, (uint32_t)i); return true; }, &sh->t);
 }
 
-// M = F^-1 X for the 3x3 frame F = [a0 a1 an] (columns) and the three-vector X: coordinates of X in the prior frame (fp64)
-__device__ inline void frame_coordinates(const PriorRecord* pr, const double x[3], double out[3]) {
-    const double f00 = pr->a0[0], f10 = pr->a0[1], f20 = pr->a0[2];
-    const double f01 = pr->a1[0], f11 = pr->a1[1], f21 = pr->a1[2];
-    const double f02 = pr->an[0], f12 = pr->an[1], f22 = pr->an[2];
-    const double c00 = f11 * f22 - f12 * f21, c01 = f12 * f20 - f10 * f22, c02 = f10 * f21 - f11 * f20;
-    const double det = f00 * c00 + f01 * c01 + f02 * c02;
-    const double inv = det != 0.0 ? 1.0 / det : 0.0;
+// M = F^-1 X for the 3x3 frame F = [a0 a1 an] (columns) and the three-vector X: coordinates of X in the prior frame.
+// fp32 with the hardware reciprocal: the results feed checks that carry several per cent of slack (a chain of fp64
+// divisions and square roots on one lane was 1-2 us of every stage).
+__device__ inline void frame_coordinates(const PriorRecord* pr, const float x[3], float out[3]) {
+    const float f00 = pr->a0[0], f10 = pr->a0[1], f20 = pr->a0[2];
+    const float f01 = pr->a1[0], f11 = pr->a1[1], f21 = pr->a1[2];
+    const float f02 = pr->an[0], f12 = pr->an[1], f22 = pr->an[2];
+    const float c00 = f11 * f22 - f12 * f21, c01 = f12 * f20 - f10 * f22, c02 = f10 * f21 - f11 * f20;
+    const float det = f00 * c00 + f01 * c01 + f02 * c02;
+    const float inv = det != 0.0f ? __builtin_amdgcn_rcpf(det) : 0.0f;
     // inverse = adj / det, adj = cofactor^T
-    const double i00 = c00 * inv, i01 = (f02 * f21 - f01 * f22) * inv, i02 = (f01 * f12 - f02 * f11) * inv;
-    const double i10 = c01 * inv, i11 = (f00 * f22 - f02 * f20) * inv, i12 = (f02 * f10 - f00 * f12) * inv;
-    const double i20 = c02 * inv, i21 = (f01 * f20 - f00 * f21) * inv, i22 = (f00 * f11 - f01 * f10) * inv;
+    const float i00 = c00 * inv, i01 = (f02 * f21 - f01 * f22) * inv, i02 = (f01 * f12 - f02 * f11) * inv;
+    const float i10 = c01 * inv, i11 = (f00 * f22 - f02 * f20) * inv, i12 = (f02 * f10 - f00 * f12) * inv;
+    const float i20 = c02 * inv, i21 = (f01 * f20 - f00 * f21) * inv, i22 = (f00 * f11 - f01 * f10) * inv;
     out[0] = i00 * x[0] + i01 * x[1] + i02 * x[2];
     out[1] = i10 * x[0] + i11 * x[1] + i12 * x[2];
     out[2] = i20 * x[0] + i21 * x[1] + i22 * x[2];
@@ -743,7 +875,14 @@ __device__ void exact_plane(const Geometry& g, const Workspace& ws, int tile, Sl
     const int64_t first = (int64_t)tile * g.blocks_per_tile;
     if (threadIdx.x < kPartial) {
         double running = 0.0;
-        for (int64_t b = 0; b < g.blocks_per_tile; ++b) running += get(&ws.partial[(first + b) * kPartial + threadIdx.x]);
+        for (int64_t b0 = 0; b0 < g.blocks_per_tile; b0 += 16) {      // sixteen loads in flight, added in index order
+            double part[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) part[u] = b0 + u < g.blocks_per_tile ? get(&ws.partial[(first + b0 + u) * kPartial + threadIdx.x]) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (b0 + u < g.blocks_per_tile) running += part[u];
+        }
         sh->t.mom[threadIdx.x] = running;
     }
     if (threadIdx.x == kPartial) sh->t.mom[kPartial] = (double)g.pixels;
@@ -789,6 +928,53 @@ __device__ void exact_plane(const Geometry& g, const Workspace& ws, int tile, Sl
     __syncthreads();
 }
 
+// The proof obligations of an angle slot that do not depend on the answer, and the key range its candidates can span
+// (one thread).  check[0..1]: keys of the mapped boundaries, check[2..3]: 1 if that side is open.
+__device__ inline bool phi_slot_check(const PriorRecord* pr, const float (&v)[6], int j, double (&check)[8]) {
+    // the prior frame against the exact plane: V = F M; in-plane part Rt (t = Rt th + nu w), tilt nu
+    float m0[3], m1[3];
+    const float v0[3] = {v[0], v[2], v[4]}, v1[3] = {v[1], v[3], v[5]};
+    frame_coordinates(pr, v0, m0);
+    frame_coordinates(pr, v1, m1);
+    const float r00 = m0[0], r01 = m0[1], r10 = m1[0], r11 = m1[1], nu0 = m0[2], nu1 = m1[2];
+    const float det = r00 * r11 - r01 * r10;
+    const float nu = __builtin_amdgcn_sqrtf(nu0 * nu0 + nu1 * nu1);
+    const float stretch = __builtin_amdgcn_sqrtf(r00 * r00 + r01 * r01 + r10 * r10 + r11 * r11);      // >= the largest singular value of Rt
+    const float kw = get(&pr->kw), kx = get(&pr->kx);
+    bool good = det > 0.9f && stretch < 1.6f && r00 > 0.8f && r11 > 0.8f && fabsf(r01) + fabsf(r10) < 0.04f && kx >= 1.2e-3f;
+    // every kept pixel's exact angle inside (0, pi): t1 = r10 th0 + r11 th1 + nu1 w with th1 >= min(a1) |od|_1, ... (prior_kernel)
+    {
+        const float a1_min = fminf(pr->a1[0], fminf(pr->a1[1], pr->a1[2]));
+        const float a0_max = fmaxf(fabsf(pr->a0[0]), fmaxf(fabsf(pr->a0[1]), fabsf(pr->a0[2])));
+        const float an_max = fmaxf(fabsf(pr->an[0]), fmaxf(fabsf(pr->an[1]), fabsf(pr->an[2])));
+        if (!(r11 * a1_min > 1.05f * (fabsf(r10) * a0_max + nu * an_max))) good = false;
+    }
+    // the two boundaries of this slot as pass A tested them: row . od = g0 th0 + g1 th1 + g2 w = cross(d', th) + g2 w with
+    // d' = (g1, -g0).  "row . od < -m" puts the exact t clockwise of D = Rt d' as long as the margin's kw |w| covers both
+    // the row's own out-of-plane part g2 and the tilt: det (kw - |g2|) >= |Rt d'| |nu|; the fp16 rounding of the pixel is
+    // covered by kx (rows with |entries| <= 1).  The answer has to lie strictly between the keys of the two D.
+    const uint32_t open = get(&pr->open);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float* row = pr->rows[2 * j + e];
+        float gq[3];
+        frame_coordinates(pr, row, gq);
+        const float dx = gq[1], dy = -gq[0];
+        const float mx = r00 * dx + r01 * dy, my = r10 * dx + r11 * dy;
+        const bool is_open = ((open >> (2 * j + e)) & 1u) != 0;
+        check[e] = is_open ? (e ? 2.0 : 0.0) : (double)diamond_angle(my, mx);
+        check[2 + e] = is_open ? 1.0 : 0.0;
+        if (!is_open) {
+            const float dn = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+            if (!(my - 0.04f * fabsf(mx) > 0.0f)) good = false;      // a boundary outside (0, pi)
+            if (!(fmaxf(fabsf(row[0]), fmaxf(fabsf(row[1]), fabsf(row[2]))) <= 1.05f)) good = false;
+            if (!(nu * stretch * dn * 1.05f <= (kw - fabsf(gq[2])) * det)) good = false;
+        }
+    }
+    if (!(check[1] > check[0])) good = false;
+    return good;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kGroupThreads) void phi_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ SlotScratch sh;
@@ -799,73 +985,95 @@ __global__ __launch_bounds__(kGroupThreads) void phi_stage_kernel(const T* __res
     const int mode = get(&pr->mode);
     const bool stamps = j == 0;
     if (stamps) SX_STAMP(st, 8);
+    const float* c0 = ws.cand_od + ((size_t)tile * kSlots + j) * 3 * g.cap2;
+    CandPrefetch<8> pf;
+    prefetch_candidates(pf, g, c0);
+    select_prepare(&sh);
     segment_prefix(&sh, g, ws, tile, j);
     exact_plane<T>(g, ws, tile, &sh);
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = sh.vecs[i];
     if (stamps) SX_STAMP(st, 9);
     const uint32_t n = sh.seg_prefix[g.n_seg], n_raw = sh.seg_total;
     const bool use_all = sh.use_all != 0;
     const unsigned long long n_sel = sh.n_sel;
     const unsigned long long rank = nearest_rank_index(j ? 99.0 : 1.0, n_sel);      // alpha = 1 (torch_backend.py:421-422)
-    float v[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = sh.vecs[i];
     bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !use_all && !g.spec_fail && sh.seg_overflow == 0 && rank >= below && rank - below < n;
-    uint32_t* spill = ws.cand + ((size_t)tile * kSlots + j) * g.cap;
-    uint32_t answer = 0;
+    uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + j) * (g.cap2 > (uint32_t)kLdsKeys ? g.cap2 - kLdsKeys : 0u);
+    uint32_t answer = 0, why = 1u;
     if (ok) {      // uniform
-        // the exact keys of the candidates
-        const float* c0 = ws.cand_od + ((size_t)tile * kSlots + j) * 3 * g.cap2;
-        for_each_candidate(&sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
+        // the exact keys of the candidates and their range; one thread works out the proof obligations meanwhile
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        for_each_candidate(pf, &sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
             const uint32_t k = angle_key(od, v);
+            mn = min(mn, k);
+            mx = max(mx, k);
             if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
         });
-        if (threadIdx.x == 0) {
-            // the prior frame against the exact plane: V = F M; in-plane part Rt (t = Rt th + nu w), tilt nu
-            double m0[3], m1[3];
-            const double v0[3] = {v[0], v[2], v[4]}, v1[3] = {v[1], v[3], v[5]};
-            frame_coordinates(pr, v0, m0);
-            frame_coordinates(pr, v1, m1);
-            const double r00 = m0[0], r01 = m0[1], r10 = m1[0], r11 = m1[1], nu0 = m0[2], nu1 = m1[2];
-            const double det = r00 * r11 - r01 * r10;
-            const double nu = sqrt(nu0 * nu0 + nu1 * nu1);
-            const double stretch = sqrt(r00 * r00 + r01 * r01 + r10 * r10 + r11 * r11);      // >= the largest singular value of Rt
-            bool good = det > 0.9 && stretch < 1.6 && fabs(r01) + fabs(r10) < 0.08 && nu * stretch * 1.05 <= (double)get(&pr->kw) * det;
-            // the boundaries of this slot, mapped: D = Rt d; the answer has to lie strictly between their keys
-            const uint32_t open = get(&pr->open);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const double dx = get(&pr->bd[2 * j + e][0]), dy = get(&pr->bd[2 * j + e][1]);
-                const double mx = r00 * dx + r01 * dy, my = r10 * dx + r11 * dy;
-                sh.check[e] = (double)diamond_angle((float)my, (float)mx);
-                if (((open >> (2 * j + e)) & 1u) == 0 && !(my - 0.04 * fabs(mx) > 0.0)) good = false;      // a boundary outside (0, pi)
-            }
-            sh.check[2] = ((open >> (2 * j)) & 1u) ? 1.0 : 0.0;
-            sh.check[3] = ((open >> (2 * j + 1)) & 1u) ? 1.0 : 0.0;
-            sh.ok = good ? 1 : 0;
-        }
+        publish_range(&sh, mn, mx);
+        if (threadIdx.x == kGroupThreads - 1) sh.ok = phi_slot_check(pr, v, j, sh.check) ? 1 : 0;
         __syncthreads();
+        if (stamps) SX_STAMP(st, 10);
         ok = sh.ok != 0;
+        why = 2u;
     }
-    if (stamps) SX_STAMP(st, 10);
     if (ok) {
-        answer = select_slot_keys(&sh, spill, n, (uint32_t)(rank - below));
+        // (the histogram is NOT filled on the way: consecutive candidates are neighbours in the image with nearly the same key,
+        // and a wave's LDS atomics on one bin take their turns -- 5 us against 2 us for the sweep over contiguous shares)
+        answer = select_slot_keys(&sh, spill, n, (uint32_t)(rank - below), false);
         const float a = key_float(answer);
         const double slack = 4e-6;
         if (sh.check[2] == 0.0 && !((double)a >= sh.check[0] + slack)) ok = false;
         if (sh.check[3] == 0.0 && !((double)a <= sh.check[1] - slack)) ok = false;
+        why = 3u;
     }
     if (!ok) {      // the speculation did not hold for this slot (or was never made): every key of the tile, exact and slow
         __syncthreads();
-        if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << j);
+        if (threadIdx.x == 0) {
+            atomicOr(&st.fell_back, 1u << j);
+            atomicOr(&st.spec, (sh.seg_overflow ? 4u : why) << (8 + 4 * j));      // diagnostic: why (1 preconditions, 2 frame / boundaries, 3 answer outside, 4 segment overflow)
+        }
         reset_scratch(&sh.t);
         answer = select_whole_group<T>(images, g, tile, j, rank, v, use_all, &sh.t);
     }
     if (threadIdx.x == 0) {
         put(&st.phi_key[j], answer);
         put(&st.rank[j], rank);
-        put(&st.ncand_seen[j], n_raw);
+        put(&st.ncand_seen[j], mode == 0 ? n_raw : 0u);
     }
     if (stamps) SX_STAMP(st, 11);
+}
+
+// The same for a concentration slot: the cone check, the bound Theta every non-candidate stays below, and the range of the bins.
+__device__ inline bool conc_slot_check(const PriorRecord* pr, const float (&pinv)[6], int j, double& theta_out, float& hi_out) {
+    // row j of the pseudo-inverse in the prior frame: with q = F^T x = (th0, th1, w) and x = F^-T q, p . x = (F^-1 p) . q
+    const float p[3] = {pinv[3 * j], pinv[3 * j + 1], pinv[3 * j + 2]};
+    float gq[3], g1[3], g2[3];
+    frame_coordinates(pr, p, gq);
+    // the slot's two test rows the same way: row_e . od = u_e . th + gamma_e w, threshold T_e = -row_e[3]
+    const float* row1 = pr->rows[kRowConc + 2 * j];
+    const float* row2 = pr->rows[kRowConc + 2 * j + 1];
+    frame_coordinates(pr, row1, g1);
+    frame_coordinates(pr, row2, g2);
+    const float u1x = g1[0], u1y = g1[1], t1 = -row1[3], u2x = g2[0], u2y = g2[1], t2 = -row2[3];
+    const float det = u1x * u2y - u1y * u2x;
+    const float kw = get(&pr->kw), kx = get(&pr->kx);
+    if (!(fabsf(det) > 1e-7f)) return false;
+    // (g0, g1) = alpha u1 + beta u2 with alpha, beta >= 0 (inside the cone): a pixel that failed both tests has
+    // p . od < alpha T1 + beta T2 - (alpha + beta) m + (alpha |gamma1| + beta |gamma2| + |g2|) |w| + rounding
+    const float inv = __builtin_amdgcn_rcpf(det);
+    const float alpha = (gq[0] * u2y - gq[1] * u2x) * inv, beta = (u1x * gq[1] - u1y * gq[0]) * inv;
+    const float l1 = fabsf(p[0]) + fabsf(p[1]) + fabsf(p[2]);
+    const float rmax = fmaxf(fmaxf(fabsf(row1[0]), fmaxf(fabsf(row1[1]), fabsf(row1[2]))), fmaxf(fabsf(row2[0]), fmaxf(fabsf(row2[1]), fabsf(row2[2]))));
+    // (alpha, beta carry ~1e-6 of rounding: a cone edge case fails the check rather than passing it by luck)
+    const bool good = alpha >= 1e-5f * l1 && beta >= 1e-5f * l1 && rmax <= 1.05f && kx >= 1.2e-3f &&
+                      (alpha + beta) * kw >= 1.05f * (alpha * fabsf(g1[2]) + beta * fabsf(g2[2]) + fabsf(gq[2])) && (alpha + beta) * (kx - 1.1e-3f) >= 3e-6f * l1 && t1 < 1e30f && t2 < 1e30f;
+    theta_out = (double)alpha * (double)t1 + (double)beta * (double)t2;
+    // the largest value the sample saw, with room: keys beyond it share the last bin
+    const float span = alpha * fmaxf(get(&pr->cmax[2 * j]) - t1, 0.0f) + beta * fmaxf(get(&pr->cmax[2 * j + 1]) - t2, 0.0f);
+    hi_out = (float)theta_out + fmaxf(1.25f * span, 1e-3f * fabsf((float)theta_out) + 1e-6f);
+    return good;
 }
 
 template <typename T>
@@ -878,8 +1086,12 @@ __global__ __launch_bounds__(kGroupThreads) void conc_stage_kernel(const T* __re
     const int mode = get(&pr->mode);
     const bool stamps = j == 0;
     if (stamps) SX_STAMP(st, 12);
-    segment_prefix(&sh, g, ws, tile, slot);
-    if (threadIdx.x == 0) {
+    const float* c0 = ws.cand_od + ((size_t)tile * kSlots + slot) * 3 * g.cap2;
+    CandPrefetch<16> pf;
+    prefetch_candidates(pf, g, c0);
+    select_prepare(&sh);
+    segment_prefix(&sh, g, ws, tile, slot);      // (wave 0)
+    if (threadIdx.x == kWave) {                  // (wave 1, meanwhile)
         float vecs[6], he[6], pinv[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) vecs[i] = get(&st.vecs[i]);
@@ -889,6 +1101,11 @@ __global__ __launch_bounds__(kGroupThreads) void conc_stage_kernel(const T* __re
             sh.pinv[i] = pinv[i];
             sh.he[i] = he[i];
         }
+        double theta = 0.0;
+        float hi = 0.0f;
+        const bool good = mode == 0 && conc_slot_check(pr, pinv, j, theta, hi);
+        sh.check[0] = theta;
+        sh.ok = good ? 1 : 0;
     }
     __syncthreads();
     float pinv[6];
@@ -901,49 +1118,34 @@ __global__ __launch_bounds__(kGroupThreads) void conc_stage_kernel(const T* __re
     // every pixel that is not a candidate lies below the answer (that is what gets proved): the answer's rank among the candidates
     const unsigned long long outside = n_all - (unsigned long long)n;
     bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !g.spec_fail && sh.seg_overflow == 0 && k99 >= outside && n > 0;
-    uint32_t* spill = ws.cand + ((size_t)tile * kSlots + slot) * g.cap;
+    uint32_t why = ok && sh.ok == 0 ? 2u : 1u;
+    ok = ok && sh.ok != 0;
+    uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + slot) * (g.cap2 > (uint32_t)kLdsKeys ? g.cap2 - kLdsKeys : 0u);
     uint32_t answer = 0;
     if (ok) {
-        const float* c0 = ws.cand_od + ((size_t)tile * kSlots + slot) * 3 * g.cap2;
-        for_each_candidate(&sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        for_each_candidate(pf, &sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
             float ca, cb;
             concentration(od, pinv, ca, cb);
             const uint32_t k = float_key(j ? cb : ca);
+            mn = min(mn, k);
+            mx = max(mx, k);
             if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
         });
-        if (threadIdx.x == 0) {
-            // row j of the pseudo-inverse in the prior frame: p . x = g0 th0 + g1 th1 + g2 w
-            const double p[3] = {pinv[3 * j], pinv[3 * j + 1], pinv[3 * j + 2]};
-            // p . x = (F^-1 ... ) careful: p . x = p^T F^-T F^T x, so the coordinates are F^-1 applied to ... the TRANSPOSE: solve F^T c = ... see below
-            // With q = F^T x (th0, th1, w) and x = F^-T q:  p . x = (F^-1 p) . q.
-            double gq[3];
-            frame_coordinates(pr, p, gq);
-            const double u1x = get(&pr->cd[2 * j][0]), u1y = get(&pr->cd[2 * j][1]), t1 = get(&pr->cd[2 * j][2]);
-            const double u2x = get(&pr->cd[2 * j + 1][0]), u2y = get(&pr->cd[2 * j + 1][1]), t2 = get(&pr->cd[2 * j + 1][2]);
-            const double det = u1x * u2y - u1y * u2x;
-            bool good = false;
-            double theta = 0.0;
-            if (fabs(det) > 1e-12) {
-                const double alpha = (gq[0] * u2y - gq[1] * u2x) / det, beta = (u1x * gq[1] - u1y * gq[0]) / det;
-                const double l1 = fabs(p[0]) + fabs(p[1]) + fabs(p[2]);
-                good = alpha >= 0.0 && beta >= 0.0 && (alpha + beta) * (double)get(&pr->kw) >= 1.05 * fabs(gq[2]) && (alpha + beta) * (double)get(&pr->kx) >= 3e-6 * l1 && t1 > -1e30 && t2 > -1e30;
-                theta = alpha * t1 + beta * t2;
-            }
-            sh.check[0] = theta;
-            sh.ok = good ? 1 : 0;
-        }
+        publish_range(&sh, mn, mx);
         __syncthreads();
-        ok = sh.ok != 0;
-    }
-    if (stamps) SX_STAMP(st, 14);
-    if (ok) {
-        answer = select_slot_keys(&sh, spill, n, (uint32_t)(k99 - outside));
+        if (stamps) SX_STAMP(st, 14);
+        answer = select_slot_keys(&sh, spill, n, (uint32_t)(k99 - outside), false);
         const double a = (double)key_float(answer), theta = sh.check[0];
         if (!(a >= theta + 4e-6 * fabs(theta) + 1e-7)) ok = false;
+        why = 3u;
     }
     if (!ok) {
         __syncthreads();
-        if (threadIdx.x == 0) atomicOr(&st.fell_back, 1u << slot);
+        if (threadIdx.x == 0) {
+            atomicOr(&st.fell_back, 1u << slot);
+            atomicOr(&st.spec, (sh.seg_overflow ? 4u : why) << (8 + 4 * slot));
+        }
         reset_scratch(&sh.t);
         answer = select_whole_group<T>(images, g, tile, slot, k99, pinv, true, &sh.t);
     }
@@ -951,7 +1153,7 @@ __global__ __launch_bounds__(kGroupThreads) void conc_stage_kernel(const T* __re
         const float mc = key_float(answer);
         put(&st.max_c[j], mc);
         put(&st.rank[slot], k99);
-        put(&st.ncand_seen[slot], n_raw);
+        put(&st.ncand_seen[slot], mode == 0 ? n_raw : 0u);
         StageRecord* rec = &st.rec[2];
         put(&rec->scale[j], target_max_conc[j] / mc);      // torch_backend.py:452
         if (j == 0) {

@@ -29,4 +29,6 @@ px = n * h * w
 print(json.dumps({"shape": [n, 3, h, w], "dtype": str(dt), "two_pass_us": round(t2, 1), "four_pass_us": round(t1, 1), "bitwise_equal": same,
                   "two_pass_MPs": round(px / t2, 0), "fell_back_tiles": int((p2["fell_back"] != 0).sum()),
                   "candidates_pct_per_slot": [round(float(v), 2) for v in (p2["n_candidates"].double().mean(0) / (h * w) * 100)],
-                  "stamps_us_median(prior 0-7, phi 8-11, conc 12-15)": [round(float(v), 1) for v in p2["stamps_us"].median(0).values]}))
+                  "stamps_us_median(prior 0-7, phi 8-11, conc 12-15)": [round(float(v), 1) for v in p2["stamps_us"].median(0).values],
+                  "conc_us_per_tile(sorted)": [round(float(v), 1) for v in (p2["stamps_us"][:, 15] - p2["stamps_us"][:, 12]).sort().values[::8]],
+                  "phi_us_per_tile(sorted)": [round(float(v), 1) for v in (p2["stamps_us"][:, 11] - p2["stamps_us"][:, 8]).sort().values[::8]]}))
