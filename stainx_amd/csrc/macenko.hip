@@ -77,6 +77,7 @@ struct alignas(256) GroupState {
     int32_t use_all;
     uint32_t fell_back;           // bit s: slot s used the whole-group radix select; bit 4+s: candidate radix select
     uint32_t spec;                // two-pass transform (macenko_twopass.hpp): kSpecSlow | kSpecHazard
+    unsigned long long phi_pub[2];      // two-pass transform: {tag, angle key} granules the two stage workgroups of a tile hand each other
     unsigned long long stamp[16]; // diagnostic: wall_clock64() at stage boundaries of the per-tile stages
 };
 
@@ -2414,8 +2415,7 @@ static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws,
     else
         hipLaunchKernelGGL((prior_kernel<T, false, kInter>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
     hipLaunchKernelGGL((pass_a_kernel<T, V, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
-    hipLaunchKernelGGL((phi_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws);
-    hipLaunchKernelGGL((conc_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
+    hipLaunchKernelGGL((estimate_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
     return check_launch("macenko two-pass estimate");
 }
 

@@ -15,10 +15,9 @@
 //   K1 pass_a_kernel  the moments exactly as stats_kernel accumulates them + per pixel eight half-plane tests in the
 //                     prior frame; pixels that pass none are only counted, the others (~9 %) are queued in LDS and
 //                     written out per slot as optical-density triples                            (one read of the input)
-//   K2 phi_stage      two workgroups per tile (one per angle percentile): exact plane from the moments, exact keys of
-//                     the slot's candidates, exact order statistic, proof
-//   K3 conc_stage     two workgroups per tile (one per concentration): stain vectors, pseudo-inverse, exact keys, exact
-//                     order statistic, proof, scale
+//   K2 estimate_stage two workgroups per tile: exact plane from the moments; workgroup j: exact keys of the candidates of
+//                     angle percentile j, exact order statistic, proof; hand-off of the two keys between the partners;
+//                     stain vectors, pseudo-inverse; the same for concentration j; scale
 //   reconstruct_kernel (unchanged)                                                  (one read + one write of the input)
 //
 // Why the proofs hold.  Let V be the exact plane (fp32, as the classic path computes it) and F the prior frame; with
@@ -161,6 +160,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         put(&st.below[tid], 0u);
         put(&st.ncand_seen[tid], 0u);
     }
+    if (tid < 2) put(&st.phi_pub[tid], 0ull);
     if (tid == 0) {
         put(&st.fell_back, 0u);
         put(&st.spec, 0u);
@@ -675,6 +675,8 @@ struct alignas(16) SlotScratch {
     int ok, use_all;
     unsigned long long n_sel;
     uint32_t seg_prefix[kMaxSegments + 1], seg_total, seg_overflow;
+    uint32_t own_key;
+    int partner_ok;
 };
 
 // The slot's candidates lie in one segment per wave of pass A: prefix sums of the segment fills (one wave, four segments per
@@ -975,76 +977,6 @@ __device__ inline bool phi_slot_check(const PriorRecord* pr, const float (&v)[6]
     return good;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kGroupThreads) void phi_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
-    __shared__ SlotScratch sh;
-    const int tile = blockIdx.x >> 1, j = blockIdx.x & 1;
-    GroupState& st = ws.state[tile];
-    const PriorRecord* pr = &ws.prior[tile];
-    const uint32_t below = get(&st.below[j]), spec = get(&st.spec);
-    const int mode = get(&pr->mode);
-    const bool stamps = j == 0;
-    if (stamps) SX_STAMP(st, 8);
-    const float* c0 = ws.cand_od + ((size_t)tile * kSlots + j) * 3 * g.cap2;
-    CandPrefetch<8> pf;
-    prefetch_candidates(pf, g, c0);
-    select_prepare(&sh);
-    segment_prefix(&sh, g, ws, tile, j);
-    exact_plane<T>(g, ws, tile, &sh);
-    float v[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = sh.vecs[i];
-    if (stamps) SX_STAMP(st, 9);
-    const uint32_t n = sh.seg_prefix[g.n_seg], n_raw = sh.seg_total;
-    const bool use_all = sh.use_all != 0;
-    const unsigned long long n_sel = sh.n_sel;
-    const unsigned long long rank = nearest_rank_index(j ? 99.0 : 1.0, n_sel);      // alpha = 1 (torch_backend.py:421-422)
-    bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !use_all && !g.spec_fail && sh.seg_overflow == 0 && rank >= below && rank - below < n;
-    uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + j) * (g.cap2 > (uint32_t)kLdsKeys ? g.cap2 - kLdsKeys : 0u);
-    uint32_t answer = 0, why = 1u;
-    if (ok) {      // uniform
-        // the exact keys of the candidates and their range; one thread works out the proof obligations meanwhile
-        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-        for_each_candidate(pf, &sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
-            const uint32_t k = angle_key(od, v);
-            mn = min(mn, k);
-            mx = max(mx, k);
-            if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
-        });
-        publish_range(&sh, mn, mx);
-        if (threadIdx.x == kGroupThreads - 1) sh.ok = phi_slot_check(pr, v, j, sh.check) ? 1 : 0;
-        __syncthreads();
-        if (stamps) SX_STAMP(st, 10);
-        ok = sh.ok != 0;
-        why = 2u;
-    }
-    if (ok) {
-        // (the histogram is NOT filled on the way: consecutive candidates are neighbours in the image with nearly the same key,
-        // and a wave's LDS atomics on one bin take their turns -- 5 us against 2 us for the sweep over contiguous shares)
-        answer = select_slot_keys(&sh, spill, n, (uint32_t)(rank - below), false);
-        const float a = key_float(answer);
-        const double slack = 4e-6;
-        if (sh.check[2] == 0.0 && !((double)a >= sh.check[0] + slack)) ok = false;
-        if (sh.check[3] == 0.0 && !((double)a <= sh.check[1] - slack)) ok = false;
-        why = 3u;
-    }
-    if (!ok) {      // the speculation did not hold for this slot (or was never made): every key of the tile, exact and slow
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicOr(&st.fell_back, 1u << j);
-            atomicOr(&st.spec, (sh.seg_overflow ? 4u : why) << (8 + 4 * j));      // diagnostic: why (1 preconditions, 2 frame / boundaries, 3 answer outside, 4 segment overflow)
-        }
-        reset_scratch(&sh.t);
-        answer = select_whole_group<T>(images, g, tile, j, rank, v, use_all, &sh.t);
-    }
-    if (threadIdx.x == 0) {
-        put(&st.phi_key[j], answer);
-        put(&st.rank[j], rank);
-        put(&st.ncand_seen[j], mode == 0 ? n_raw : 0u);
-    }
-    if (stamps) SX_STAMP(st, 11);
-}
-
 // The same for a concentration slot: the cone check, the bound Theta every non-candidate stays below, and the range of the bins.
 __device__ inline bool conc_slot_check(const PriorRecord* pr, const float (&pinv)[6], int j, double& theta_out, float& hi_out) {
     // row j of the pseudo-inverse in the prior frame: with q = F^T x = (th0, th1, w) and x = F^-T q, p . x = (F^-1 p) . q
@@ -1076,26 +1008,100 @@ __device__ inline bool conc_slot_check(const PriorRecord* pr, const float (&pinv
     return good;
 }
 
+// K2: both per-tile stages in ONE launch, two workgroups per tile.  Workgroup j works out angle percentile j, hands its key
+// to its partner through an 8-byte {key, tag} granule (one agent-scope store, polled with agent-scope loads: the form
+// MI355X_MICROARCH.md lists as needing no further ordering), then works out concentration j -- whose candidates it requested
+// before it started to wait.  As two launches the stages cost a kernel boundary plus ~3.5 us of launch ramp more, and the
+// second could not start its loads early.  The wait is bounded: a partner that does not show up (it would have to be
+// unscheduled while this workgroup spins -- the pair has adjacent block indices) is replaced by the slow exact select here.
 template <typename T>
-__global__ __launch_bounds__(kGroupThreads) void conc_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc) {
+__global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc) {
     __shared__ SlotScratch sh;
     const int tile = blockIdx.x >> 1, j = blockIdx.x & 1, slot = 2 + j;
     GroupState& st = ws.state[tile];
     const PriorRecord* pr = &ws.prior[tile];
-    const uint32_t spec = get(&st.spec);
+    const uint32_t below = get(&st.below[j]), spec = get(&st.spec);
     const int mode = get(&pr->mode);
     const bool stamps = j == 0;
+    if (stamps) SX_STAMP(st, 8);
+    const float* c0 = ws.cand_od + ((size_t)tile * kSlots + j) * 3 * g.cap2;
+    const size_t spill_words = g.cap2 > (uint32_t)kLdsKeys ? g.cap2 - kLdsKeys : 0u;
+    float v[6];
+    bool use_all;
+    unsigned long long rank_other;
+    {   // ------------------------------------------------ angle percentile j
+        CandPrefetch<8> pf;
+        prefetch_candidates(pf, g, c0);
+        select_prepare(&sh);
+        segment_prefix(&sh, g, ws, tile, j);
+        exact_plane<T>(g, ws, tile, &sh);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = sh.vecs[i];
+        if (stamps) SX_STAMP(st, 9);
+        const uint32_t n = sh.seg_prefix[g.n_seg], n_raw = sh.seg_total;
+        use_all = sh.use_all != 0;
+        const unsigned long long n_sel = sh.n_sel;
+        const unsigned long long rank = nearest_rank_index(j ? 99.0 : 1.0, n_sel);      // alpha = 1 (torch_backend.py:421-422)
+        rank_other = nearest_rank_index(j ? 1.0 : 99.0, n_sel);
+        bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !use_all && !g.spec_fail && sh.seg_overflow == 0 && rank >= below && rank - below < n;
+        uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + j) * spill_words;
+        uint32_t answer = 0, why = 1u;
+        if (ok) {      // uniform
+            // the exact keys of the candidates and their range; one thread works out the proof obligations meanwhile
+            uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+            for_each_candidate(pf, &sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
+                const uint32_t k = angle_key(od, v);
+                mn = min(mn, k);
+                mx = max(mx, k);
+                if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
+            });
+            publish_range(&sh, mn, mx);
+            if (threadIdx.x == kGroupThreads - 1) sh.ok = phi_slot_check(pr, v, j, sh.check) ? 1 : 0;
+            __syncthreads();
+            if (stamps) SX_STAMP(st, 10);
+            ok = sh.ok != 0;
+            why = 2u;
+        }
+        if (ok) {
+            // (the histogram is NOT filled on the way: consecutive candidates are neighbours in the image with nearly the same
+            // key, and a wave's LDS atomics on one bin take their turns -- 5 us against 2 us for the sweep over contiguous shares)
+            answer = select_slot_keys(&sh, spill, n, (uint32_t)(rank - below), false);
+            const float a = key_float(answer);
+            const double slack = 4e-6;
+            if (sh.check[2] == 0.0 && !((double)a >= sh.check[0] + slack)) ok = false;
+            if (sh.check[3] == 0.0 && !((double)a <= sh.check[1] - slack)) ok = false;
+            why = 3u;
+        }
+        if (!ok) {      // the speculation did not hold for this slot (or was never made): every key of the tile, exact and slow
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                atomicOr(&st.fell_back, 1u << j);
+                atomicOr(&st.spec, (sh.seg_overflow ? 4u : why) << (8 + 4 * j));      // diagnostic: why (1 preconditions, 2 frame / boundaries, 3 answer outside, 4 segment overflow)
+            }
+            reset_scratch(&sh.t);
+            answer = select_whole_group<T>(images, g, tile, j, rank, v, use_all, &sh.t);
+        }
+        if (threadIdx.x == 0) {
+            put(&st.phi_key[j], answer);
+            put(&st.rank[j], rank);
+            put(&st.ncand_seen[j], mode == 0 ? n_raw : 0u);
+            __hip_atomic_store(&st.phi_pub[j], (1ull << 32) | (unsigned long long)answer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the hand-off granule
+            sh.own_key = answer;
+        }
+        if (stamps) SX_STAMP(st, 11);
+    }
+    // ------------------------------------------------ concentration j
     if (stamps) SX_STAMP(st, 12);
-    const float* c0 = ws.cand_od + ((size_t)tile * kSlots + slot) * 3 * g.cap2;
+    const float* c1 = ws.cand_od + ((size_t)tile * kSlots + slot) * 3 * g.cap2;
     CandPrefetch<16> pf;
-    prefetch_candidates(pf, g, c0);
+    prefetch_candidates(pf, g, c1);      // in flight while the partner finishes
+    __syncthreads();                     // everyone is done with the first selection's scratch
     select_prepare(&sh);
     segment_prefix(&sh, g, ws, tile, slot);      // (wave 0)
-    if (threadIdx.x == kWave) {                  // (wave 1, meanwhile)
-        float vecs[6], he[6], pinv[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) vecs[i] = get(&st.vecs[i]);
-        stain_vectors_and_pinv(vecs, get(&st.phi_key[0]), get(&st.phi_key[1]), he, pinv);
+    auto vectors_and_check = [&](uint32_t partner_key) {      // one thread
+        float he[6], pinv[6];
+        const uint32_t key0 = j == 0 ? sh.own_key : partner_key, key1 = j == 0 ? partner_key : sh.own_key;
+        stain_vectors_and_pinv(v, key0, key1, he, pinv);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             sh.pinv[i] = pinv[i];
@@ -1106,8 +1112,26 @@ __global__ __launch_bounds__(kGroupThreads) void conc_stage_kernel(const T* __re
         const bool good = mode == 0 && conc_slot_check(pr, pinv, j, theta, hi);
         sh.check[0] = theta;
         sh.ok = good ? 1 : 0;
+    };
+    if (threadIdx.x == kWave) {                  // (wave 1, meanwhile) the partner's key
+        unsigned long long granule = 0;
+        for (int spin = 0; spin < (1 << 16); ++spin) {      // (~0.1 s at the very most)
+            granule = __hip_atomic_load(&st.phi_pub[1 - j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((granule >> 32) == 1ull) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        sh.partner_ok = (granule >> 32) == 1ull ? 1 : 0;
+        if (sh.partner_ok) vectors_and_check((uint32_t)granule);
     }
     __syncthreads();
+    if (__builtin_expect(sh.partner_ok == 0, 0)) {      // uniform; the partner never showed up: its percentile, the slow way
+        reset_scratch(&sh.t);
+        const uint32_t partner_key = select_whole_group<T>(images, g, tile, 1 - j, rank_other, v, use_all, &sh.t);
+        __syncthreads();
+        select_prepare(&sh);
+        if (threadIdx.x == kWave) vectors_and_check(partner_key);
+        __syncthreads();
+    }
     float pinv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) pinv[i] = sh.pinv[i];
@@ -1120,11 +1144,11 @@ __global__ __launch_bounds__(kGroupThreads) void conc_stage_kernel(const T* __re
     bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !g.spec_fail && sh.seg_overflow == 0 && k99 >= outside && n > 0;
     uint32_t why = ok && sh.ok == 0 ? 2u : 1u;
     ok = ok && sh.ok != 0;
-    uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + slot) * (g.cap2 > (uint32_t)kLdsKeys ? g.cap2 - kLdsKeys : 0u);
+    uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + slot) * spill_words;
     uint32_t answer = 0;
     if (ok) {
         uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-        for_each_candidate(pf, &sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
+        for_each_candidate(pf, &sh, g, c1, [&](uint32_t i, const float (&od)[3]) {
             float ca, cb;
             concentration(od, pinv, ca, cb);
             const uint32_t k = float_key(j ? cb : ca);
