@@ -48,7 +48,10 @@ typedef enum {
                                        SX_MACENKO_NORMALIZE_0_1 `transform(x, normalize_to_0_1).to(bfloat16)` -- so a uint8 tile from the decoder
                                        becomes a model's bf16 input with 3 bytes read and 6 written per pixel (an extension: SURVEY.md 8f-2) */
 #define SX_MACENKO_OUT_F16 64u       /* the same with float16 */
-#define SX_MACENKO_CLASSIC 16u       /* the four-pass form of the transform instead of the two-pass one (same bits; A/B runs, tests) */
+#define SX_MACENKO_CLASSIC 16u       /* the four-pass form of the transform even where the two-pass form would be chosen (same bits; A/B runs, tests,
+                                       callers whose batches hold tiles without tissue: see sx_macenko_telemetry_offset) */
+#define SX_MACENKO_TWO_PASS 256u     /* the two-pass form wherever it can run (by default only where it is the faster one: f32 / f64 batches of
+                                       >= 4 M pixels, tiles of 128x128 ... 724x724) */
 #define SX_MACENKO_SPEC_FAIL 128u    /* diagnostic: the two-pass form treats every speculation as failed (forces its slow exact path; tests) */
 #define SX_MACENKO_NO_TIE_SHORTCUT 8u /* diagnostic: do not resolve a bracket that closed on one key from its counts (forces the slow exact paths; tests) */
 #define SX_MACENKO_CHANNELS_LAST 2u /* images and output are (N,H,W,3) (decoder / PIL layout) instead of (N,3,H,W); an extension: the
@@ -70,6 +73,12 @@ size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, int64_t width
 int sx_macenko_transform(const void* images_dev, void* out_dev, int dtype, int64_t n_tiles, int64_t height,
                          int64_t width, const float* stain_matrix_dev, const float* target_max_conc_dev,
                          unsigned flags, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Byte offset, inside the workspace of the LAST sx_macenko_transform, of a uint32 that holds how many of the batch's per-tile
+ * selections left the speculative path of the two-pass form (tiles without tissue, tiles without a stable stain plane ...: each
+ * costs a whole-tile exact select, ~0.1-0.5 ms).  A host that sees it non-zero (read back asynchronously) should pass
+ * SX_MACENKO_CLASSIC for such data: the four-pass form has no such cliff.  Zero for calls that took the four-pass form. */
+size_t sx_macenko_telemetry_offset(void);
 
 /* Replaces MacenkoTorch.compute_reference_stain_matrix_torch (torch_backend.py:463-519): one stain
  * estimate pooled over all n_tiles*H*W pixels, no "<3 kept pixels" fallback.

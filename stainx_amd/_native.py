@@ -25,6 +25,7 @@ MACENKO_CLASSIC = 16
 MACENKO_OUT_BF16 = 32
 MACENKO_OUT_F16 = 64
 MACENKO_SPEC_FAIL = 128
+MACENKO_TWO_PASS = 256
 MACENKO_PARAM_FLOATS = 48
 PFIT_SUMS = 1033
 PFIT_COMPACT = 32768
@@ -42,6 +43,7 @@ SIGNATURES = {
     "sx_macenko_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _uint, _vp, _sz, _vp]),
     "sx_macenko_fit": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sx_macenko_tile_params": (_int, [_vp, _i64, _vp, _vp]),
+    "sx_macenko_telemetry_offset": (_sz, []),
     "sx_macenko_dfit_state_bytes": (_sz, []),
     "sx_macenko_dfit_moments": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sx_macenko_dfit_begin": (_int, [_vp, _vp, _vp]),
@@ -133,12 +135,21 @@ def stream_ptr(device: torch.device) -> int:
 
 
 class Scratch:
-    """Grow-only device workspace owned by torch's caching allocator (the library never allocates)."""
+    """Device workspaces owned by torch's caching allocator (the library never allocates): ONE PER STREAM, so that calls on
+    different streams (or threads on different streams) never share selection state, and a buffer that has been handed out is
+    never freed while this object lives -- a captured HIP graph, or a call still in flight, may hold its address (a superseded
+    buffer is retired, not released).  Inside a stream capture the allocation comes from the graph's private pool."""
 
     def __init__(self):
-        self._buf: torch.Tensor | None = None
+        self._bufs: dict[tuple[int, int], torch.Tensor] = {}
+        self._retired: list[torch.Tensor] = []
 
     def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
-        if self._buf is None or self._buf.device != device or self._buf.numel() < nbytes:
-            self._buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        return self._buf
+        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                self._retired.append(buf)
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf

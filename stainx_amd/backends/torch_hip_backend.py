@@ -59,6 +59,16 @@ class MacenkoHIP(TorchHIPBackendBase):
         # moments pass + one per-tile stage + reconstruct instead of four passes and three stages.  The fit is always exact.
         self._precision = precision
         self.last_workspace: torch.Tensor | None = None
+        # Feedback for the choice between the two forms of the transform (see _route / _watch): the two-pass form speculates per
+        # tile and pays a whole-tile exact select (0.1-0.5 ms) for a tile it cannot speculate on -- no tissue, no stable stain
+        # plane.  The library counts those; the count is read back asynchronously and a batch stream that produces them is
+        # switched to the four-pass form (same bits, no cliff), with an occasional probe.
+        self._tele_offset = int(self._lib.sx_macenko_telemetry_offset())
+        self._tele_host: torch.Tensor | None = None
+        self._tele_event: torch.cuda.Event | None = None
+        self._tele_stream: torch.cuda.Stream | None = None
+        self._classic_left = 0
+        self._classic_span = 32
 
     @staticmethod
     def _check_images(images: torch.Tensor, what: str) -> None:
@@ -104,11 +114,51 @@ class MacenkoHIP(TorchHIPBackendBase):
             ws = self._scratch.get(nbytes, self.device)
             flags = ((_native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0) | (_native.MACENKO_CHANNELS_LAST if channels_last else 0)
                      | (_native.MACENKO_FAST if self._precision == "fast" else 0) | int(_extra_flags))
+            routed = not (flags & (_native.MACENKO_CLASSIC | _native.MACENKO_TWO_PASS | _native.MACENKO_FAST))
+            if routed:
+                flags |= self._route()
             rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),
                                                 flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
-        _native.check(rc, "sx_macenko_transform")
+            _native.check(rc, "sx_macenko_transform")
+            if routed and not (flags & _native.MACENKO_CLASSIC):
+                self._watch(ws)
         self.last_workspace = ws
         return out
+
+    def _route(self) -> int:
+        """Flag for this call: the four-pass form while a recent call reported tiles the two-pass form could not speculate on."""
+        if torch.cuda.is_current_stream_capturing():
+            return _native.MACENKO_CLASSIC      # a captured call is replayed on data nobody has seen: the form without a cliff (and no event may be queried here)
+        if self._tele_event is not None and self._tele_event.query():
+            slow = int(self._tele_host[0])
+            self._tele_event = None
+            if slow > 0:
+                self._classic_left = self._classic_span
+                self._classic_span = min(self._classic_span * 2, 4096)      # probe again, less and less often
+            else:
+                self._classic_span = 32
+        if self._classic_left > 0:
+            self._classic_left -= 1
+            return _native.MACENKO_CLASSIC
+        return 0
+
+    def _watch(self, ws: torch.Tensor) -> None:
+        """Read the library's count of slow selections back without making anything wait: a side stream copies four bytes once the
+        call's kernels are done.  (Not inside a stream capture; advisory only -- a later call may have reset the word already.)"""
+        if self._tele_event is not None or torch.cuda.is_current_stream_capturing():
+            return
+        if self._tele_host is None:
+            self._tele_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._tele_stream = torch.cuda.Stream(self.device)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self._tele_stream.wait_event(done)
+        with torch.cuda.stream(self._tele_stream):
+            self._tele_host.copy_(ws[self._tele_offset:self._tele_offset + 4].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._tele_stream)
+        ws.record_stream(self._tele_stream)
+        self._tele_event = ev
 
     def compute_reference_stain_matrix(self, images: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """Pooled stain estimate ``(HE (3,2), maxC (2,))`` (compute_reference_stain_matrix_torch, :463-519)."""

@@ -78,6 +78,7 @@ struct alignas(256) GroupState {
     uint32_t fell_back;           // bit s: slot s used the whole-group radix select; bit 4+s: candidate radix select
     uint32_t spec;                // two-pass transform (macenko_twopass.hpp): kSpecSlow | kSpecHazard
     unsigned long long phi_pub[2];      // two-pass transform: {tag, angle key} granules the two stage workgroups of a tile hand each other
+    uint32_t slow_slots;          // two-pass transform, tile 0 only: selections of the whole batch that left the speculative path (telemetry)
     unsigned long long stamp[16]; // diagnostic: wall_clock64() at stage boundaries of the per-tile stages
 };
 
@@ -1566,6 +1567,8 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
         put(&st.use_all, sh->flag);
         put(&st.n_sel, n_sel);
         put(&st.fell_back, 0u);
+        put(&st.spec, 0u);
+        if (group == 0) put(&st.slow_slots, 0u);      // (telemetry of the two-pass form: nothing to report from here)
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
             put(&st.below[s], 0u);
@@ -2709,7 +2712,13 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     g.spec_fail = (flags & SX_MACENKO_SPEC_FAIL) ? 1 : 0;
     {
         static const bool env_classic = std::getenv("STAINX_MACENKO_CLASSIC") != nullptr;      // A/B switch for benchmarks
-        g.two_pass = (!g.fast && !(flags & SX_MACENKO_CLASSIC) && !env_classic && two_pass_size(g.pixels)) ? 1 : 0;
+        // Where the two-pass form pays (measured, tools/bench_twopass.py): 4- and 8-byte pixels in batches of at least ~4 M pixels
+        // and tiles up to ~724 x 724.  Narrow pixels (uint8 / bf16 / f16) make the four passes cheap and the two-pass form's fixed
+        // stages dominate (152 vs 122 us, 161 vs 131 us); big tiles put tens of thousands of candidates on one stage workgroup.
+        // SX_MACENKO_TWO_PASS asks for it wherever it is able to run (tests, A/B runs).
+        const bool pays = (dtype == SX_F32 || dtype == SX_F64) && g.pixels >= 16384 && g.pixels <= (1ll << 19) && n * g.pixels >= (1ll << 22);
+        const bool wanted = (flags & SX_MACENKO_TWO_PASS) != 0 || (pays && !(flags & SX_MACENKO_CLASSIC) && !env_classic);
+        g.two_pass = (!g.fast && wanted && two_pass_size(g.pixels)) ? 1 : 0;
     }
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
@@ -2748,6 +2757,8 @@ extern "C" int sx_macenko_tile_params(const void* ws_ptr, int64_t n_groups, floa
     hipLaunchKernelGGL(export_params_kernel, dim3(grid), dim3(64), 0, stream, static_cast<const GroupState*>(ws_ptr), n_groups, params_out);
     return check_launch("macenko export_params");
 }
+
+extern "C" size_t sx_macenko_telemetry_offset(void) { return offsetof(GroupState, slow_slots); }
 
 extern "C" size_t sx_macenko_dfit_state_bytes(void) { return sizeof(DFitState); }
 

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         put(&st.ncand_seen[tid], 0u);
     }
     if (tid < 2) put(&st.phi_pub[tid], 0ull);
+    if (tile == 0 && tid == 0) put(&st.slow_slots, 0u);      // (tile 0's word counts for the batch)
     if (tid == 0) {
         put(&st.fell_back, 0u);
         put(&st.spec, 0u);
@@ -1077,6 +1078,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
             if (threadIdx.x == 0) {
                 atomicOr(&st.fell_back, 1u << j);
                 atomicOr(&st.spec, (sh.seg_overflow ? 4u : why) << (8 + 4 * j));      // diagnostic: why (1 preconditions, 2 frame / boundaries, 3 answer outside, 4 segment overflow)
+                atomicAdd(&ws.state[0].slow_slots, 1u);
             }
             reset_scratch(&sh.t);
             answer = select_whole_group<T>(images, g, tile, j, rank, v, use_all, &sh.t);
@@ -1169,6 +1171,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
         if (threadIdx.x == 0) {
             atomicOr(&st.fell_back, 1u << slot);
             atomicOr(&st.spec, (sh.seg_overflow ? 4u : why) << (8 + 4 * slot));
+            atomicAdd(&ws.state[0].slow_slots, 1u);
         }
         reset_scratch(&sh.t);
         answer = select_whole_group<T>(images, g, tile, slot, k99, pinv, true, &sh.t);

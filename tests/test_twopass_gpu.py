@@ -33,7 +33,7 @@ TMC = torch.tensor([1.9705, 1.0308], dtype=torch.float32)
 
 
 def _both(be, x, **kw):
-    two = be.transform(x, SM, TMC, **kw)
+    two = be.transform(x, SM, TMC, _extra_flags=_native.MACENKO_TWO_PASS, **kw)
     p2 = be.tile_params(x.shape[0])
     classic = be.transform(x, SM, TMC, _extra_flags=_native.MACENKO_CLASSIC, **kw)
     p1 = be.tile_params(x.shape[0])
@@ -79,7 +79,7 @@ def test_failed_speculation_takes_the_exact_slow_path(be, dev):
     x = synth.as_dtype(synth.he_batch(3, 128, 128, seed0=5), torch.float32).to(dev)
     classic = be.transform(x, SM, TMC, _extra_flags=_native.MACENKO_CLASSIC)
     p1 = be.tile_params(3)
-    slow = be.transform(x, SM, TMC, _extra_flags=_native.MACENKO_SPEC_FAIL)
+    slow = be.transform(x, SM, TMC, _extra_flags=_native.MACENKO_SPEC_FAIL | _native.MACENKO_TWO_PASS)
     ps = be.tile_params(3)
     assert (ps["fell_back"] & 15).eq(15).all()
     _check_equal(slow, ps, classic, p1, "spec_fail")
@@ -105,8 +105,34 @@ def test_tiles_without_a_stable_plane_or_without_tissue(be, dev):
 
 def test_two_pass_is_deterministic_and_tile_independent(be, dev):
     x = synth.as_dtype(synth.he_batch(5, 224, 224, seed0=300), torch.bfloat16).to(dev)
-    a = be.transform(x, SM, TMC)
-    b = be.transform(x, SM, TMC)
+    a = be.transform(x, SM, TMC, _extra_flags=_native.MACENKO_TWO_PASS)
+    b = be.transform(x, SM, TMC, _extra_flags=_native.MACENKO_TWO_PASS)
     assert _same(a, b)
-    alone = be.transform(x[2:3].contiguous(), SM, TMC)
+    alone = be.transform(x[2:3].contiguous(), SM, TMC, _extra_flags=_native.MACENKO_TWO_PASS)
     assert _same(alone, a[2:3])
+
+
+def test_default_route_and_feedback(be, dev):
+    """Without a flag the library takes the two-pass form where it pays (f32 / f64, >= 4 M pixels, mid-sized tiles) and the
+    backend leaves it again when the library reports tiles it could not speculate on (here: two white tiles in the batch)."""
+    from stainx_amd.backends.torch_hip_backend import MacenkoHIP
+
+    fresh = MacenkoHIP(dev)
+    tiles = synth.he_batch(16, 512, 512, seed0=2000)
+    x = synth.as_dtype(tiles, torch.float32).to(dev)
+    out = fresh.transform(x, SM, TMC)
+    assert int(fresh.tile_params(16)["n_candidates"].sum()) > 0          # candidates exist only in the two-pass form
+    torch.cuda.synchronize()
+    fresh.transform(x, SM, TMC)
+    assert fresh._classic_left == 0
+    small = fresh.transform(x[:2].contiguous(), SM, TMC)                 # 0.5 M pixels: the four-pass form
+    assert int(fresh.tile_params(2)["n_candidates"].sum()) > 0 and _same(small, out[:2])      # (its candidate counters are the brackets')
+    tiles[3] = 250
+    tiles[9] = 250
+    xb = synth.as_dtype(tiles, torch.float32).to(dev)
+    first = fresh.transform(xb, SM, TMC)
+    torch.cuda.synchronize()
+    second = fresh.transform(xb, SM, TMC)                                # the feedback has arrived: this call is routed
+    assert fresh._classic_left > 0 and _same(first, second)
+    classic = fresh.transform(xb, SM, TMC, _extra_flags=_native.MACENKO_CLASSIC)
+    assert _same(first, classic)
