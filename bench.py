@@ -2,23 +2,35 @@
 """Headline benchmark: megapixels/s of ``Macenko.transform`` on 64x3x512x512 fp32 tiles per GPU
 (BASELINE.json configs[1]), inputs resident in HBM, reference-mode (fit once, excluded from timing).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload transform|fit_transform_pooled]
 
 For N > 1 the driver launches it under ``torch.distributed.run`` (one rank per GPU, RCCL).  Tiles are
-independent units, so every rank transforms its own 64-tile batch with no data-path collective
- and the job is weak-scaled: value = N * pixels_per_rank / max-over-ranks time.
+independent units, so every rank transforms its own tiles with no data-path collective
+and the job is weak-scaled: value = N * pixels_per_rank / max-over-ranks time.
+
+The timed loop ROTATES over two different input batches (2 x 201 MB > the 256 MiB Infinity Cache), so a call
+reads its input from HBM as a pipeline that brings fresh tiles every step does; the one-buffer figure the
+reference's harness would report (its input served by the Infinity Cache from the second call on) is kept as
+``roofline.device_ms_hot``.
 
 One JSON line on stdout (rank 0).  Besides the contract fields it carries
   roofline     -- algorithmic bytes (24 B/px: one fp32 read + one fp32 write of every pixel)
                   of one transform call / its duration measured with HIP events on the launch stream,
-                  against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md.  A transform is several launches
-                  (see `launches`); the figure prices ALL of them, not only the biggest kernel.
+                  against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md (and against its measured 6.29 TB/s
+                  copy ceiling).  A transform is several launches (see `kernel`); the figure prices ALL of them.
+                  `traffic`: HBM bytes per call from the committed rocprofv3 PMC passes of this command, cited
+                  only while the kernel sources still hash to what those passes ran (else null).
   cpu_baseline -- the CPU oracle (a numpy port of the reference's backend="torch" path) timed on this
                   box's host cores over a bounded sample of the same workload (rank 0, N=1 only).
+
+``--workload fit_transform_pooled`` (BASELINE configs[3]): every rank holds 64 tiles; one step = ONE stain estimate
+pooled over all ranks' tiles (small RCCL exchanges, ``stainx_amd.distributed``) + the transform of the local tiles to it;
+``collective_ms`` is the device time inside the collectives per step.  At N = 1 the collectives are forced through RCCL.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,7 +44,9 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_FILE = ROOT / "profiles" / "r01_macenko_cfg2_hbm_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see DESIGN.md
+COPY_CEILING_GBS = 6290.0      # MI355X_MICROARCH.md: measured float4 copy
+TRAFFIC_FILE = ROOT / "profiles" / "r02_macenko_cfg2_hbm_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/hbm_traffic.py
+KERNEL_STATS = "profiles/r02_macenko_cfg2_kernel_stats.txt"
 TILES, HEIGHT, WIDTH = 64, 512, 512
 BYTES_PER_PIXEL = 24           # fp32 in + fp32 out, 3 channels
 
@@ -40,13 +54,25 @@ BYTES_PER_PIXEL = 24           # fp32 in + fp32 out, 3 channels
 def parse() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # A step is 0.2 ms.  The boxes this was measured on stall a process for ~0.1 s now and then (seen three times in some sixty
-    # timed loops): inside 100 steps that multiplies ms_per_step by five, inside 1000 steps (0.2 s) it adds half.
+    # A step is 0.17 ms.  The boxes this was measured on stall a process for ~0.1 s now and then: inside 100 steps that
+    # multiplies ms_per_step several times, inside 1000 steps it adds half.
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", choices=("transform", "fit_transform_pooled"), default="transform")
+    ap.add_argument("--batches", type=int, default=2, help="different input batches the timed loop rotates over (1: one buffer)")
     ap.add_argument("--cpu-tiles", type=int, default=64, help="tiles of the workload the CPU baseline is timed on")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     return ap.parse_args()
+
+
+def source_hash() -> str:
+    """Hash of the kernel sources: ties a committed profile to the code it was taken from (no .git on the GPU box)."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "stainx_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".hpp"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(n_tiles: int, x_cpu: torch.Tensor, he, max_c) -> dict:
@@ -71,12 +97,31 @@ def cpu_baseline(n_tiles: int, x_cpu: torch.Tensor, he, max_c) -> dict:
 
 
 def measured_traffic():
-    """HBM bytes of one transform call from the committed PMC run of this same command (rocprofv3 cannot be nested
-    inside the timed process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes.  None if absent."""
+    """HBM bytes of one transform call from the committed PMC passes of this same command (rocprofv3 cannot be nested inside
+    the timed process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes.  None if the file is absent or was
+    taken from other kernel sources than the ones in this tree."""
     try:
-        return int(json.loads(TRAFFIC_FILE.read_text())["total_bytes"])
+        doc = json.loads(TRAFFIC_FILE.read_text())
+        if doc.get("source_hash") != source_hash():
+            return None, None
+        return int(doc["total_bytes"]), doc
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+
+
+def timed_loop(fn, steps: int, barrier):
+    """K calls of fn(i) bracketed by barrier + synchronize; wall seconds and the HIP-event time of every call (ms)."""
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    out = None
+    for i in range(steps):
+        out = fn(i)
+        ev[i + 1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)], out
 
 
 def main() -> None:
@@ -89,14 +134,22 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or bool(os.environ.get("STAINX_BENCH_FORCE_DIST"))      # (the env switch lets a one-GPU box run the RCCL code path)
+    pooled = args.workload == "fit_transform_pooled"
+    if pooled and world == 1:      # a one-GPU box still runs the RCCL path: a process group of one rank, collectives forced
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["STAINX_FORCE_COLLECTIVES"] = "1"
+    distributed = world > 1 or pooled or bool(os.environ.get("STAINX_BENCH_FORCE_DIST"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if world == 1:
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import __graft_entry__ as entry
 
@@ -106,58 +159,112 @@ def main() -> None:
         dist.barrier()
 
     from stainx_amd import Macenko, synth
-
-    # synthetic Beer-Lambert tiles: rank r uses seeds 1000+64r ...
-    src_u8 = synth.he_batch(TILES, HEIGHT, WIDTH, seed0=1000 + TILES * rank)
-    x_cpu = synth.as_dtype(src_u8, torch.float32)
-    x = x_cpu.to(dev)
-    norm = Macenko(device=dev, backend="torch_hip")
-    norm.fit(synth.reference_tile(HEIGHT, WIDTH).to(dev))          # reference mode: fit once, not timed
+    from stainx_amd import distributed as sxd
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        out = norm.transform(x)
-    barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(args.steps):
-        out = norm.transform(x)
-        ev[i + 1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def max_over_ranks(seconds: float) -> float:
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    # synthetic Beer-Lambert tiles: rank r, batch b uses seeds 1000 + 64 (r + world b) ...
+    n_batches = max(1, args.batches)
+    x_cpu = synth.as_dtype(synth.he_batch(TILES, HEIGHT, WIDTH, seed0=1000 + TILES * rank), torch.float32)
+    batches = [x_cpu.to(dev)]
+    for b in range(1, n_batches):
+        batches.append(synth.as_dtype(synth.he_batch(TILES, HEIGHT, WIDTH, seed0=1000 + TILES * (rank + world * b)), torch.float32).to(dev))
+    pixels = TILES * HEIGHT * WIDTH
+
+    if pooled:
+        from stainx_amd.backends.torch_hip_backend import MacenkoHIP
+
+        be = MacenkoHIP(dev)
+
+        def step(i):
+            return sxd.macenko_fit_transform_pooled(batches[i % n_batches], steps=be)[0]
+
+        for i in range(args.warmup):
+            step(i)
+        elapsed, step_ms, out = timed_loop(step, args.steps, barrier)
+        elapsed = max_over_ranks(elapsed)
+        probe = min(args.steps, 50)
+        with sxd.collective_timer() as timer:
+            for i in range(probe):
+                step(i)
+        collective_ms = timer.ms() / probe
+        n_collectives = timer.count() // probe
+        if rank == 0:
+            dev_ms = sum(step_ms) / len(step_ms)
+            line = {
+                "metric": "megapixels/sec Macenko batch-mode fit_transform, 64x3x512x512 fp32 per GPU, stain estimate pooled over all GPUs",
+                "value": round(world * pixels / 1e6 / (elapsed / args.steps), 1), "unit": "megapixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"Macenko batch-mode fit_transform, {world * TILES}x3x512x512 fp32 sharded over {world} GPU(s) with RCCL statistics exchanges (BASELINE configs[3] is this at 8 GPUs)",
+                           "tiles_per_gpu": TILES, "height": HEIGHT, "width": WIDTH, "input_batches_rotated": n_batches,
+                           "parallelism": f"tiles sharded over {world} GPU(s); pooled fit: 1 all-reduce of 10 fp64 moments, 1 all-gather of 48 KB samples, then per percentile stage 1 all-reduce of ~8 KB int64 counts + 2 all-gathers of <= 32 KB candidate keys; transform local"},
+                "collective_ms": round(collective_ms, 4), "collectives_per_step": n_collectives, "backend": dist.get_backend(),
+                "roofline": {"bound": "hbm", "achieved": round(pixels * BYTES_PER_PIXEL / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(pixels * BYTES_PER_PIXEL / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                             "algorithmic_bytes_per_launch": pixels * BYTES_PER_PIXEL, "device_ms_per_call": round(dev_ms, 4),
+                             "kernel": "pooled fit (stats, bracket passes, pool kernels, per-group stages; host choreography with six small collectives) + transform of the local tiles"},
+            }
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+            print(json.dumps(line), flush=True)
+            os.dup2(2, 1)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    norm = Macenko(device=dev, backend="torch_hip")
+    norm.fit(synth.reference_tile(HEIGHT, WIDTH).to(dev))          # reference mode: fit once, not timed
+
+    for i in range(args.warmup):
+        out = norm.transform(batches[i % n_batches])
+    elapsed, step_ms, out = timed_loop(lambda i: norm.transform(batches[i % n_batches]), args.steps, barrier)
+    last_batch = (args.steps - 1) % n_batches
+    elapsed = max_over_ranks(elapsed)
+    # the one-buffer figure (input resident in the Infinity Cache between calls), a shorter loop
+    hot_steps = min(args.steps, 300)
+    for _ in range(20):
+        norm.transform(batches[0])
+    _, hot_ms, _ = timed_loop(lambda i: norm.transform(batches[0]), hot_steps, barrier)
     dev_ms = sum(step_ms) / len(step_ms)
     dev_std = (sum((v - dev_ms) ** 2 for v in step_ms) / max(len(step_ms) - 1, 1)) ** 0.5
 
     if rank == 0:
-        pixels = TILES * HEIGHT * WIDTH
         ms_per_step = elapsed / args.steps * 1e3
         value = world * pixels / 1e6 / (elapsed / args.steps)
         achieved = pixels * BYTES_PER_PIXEL / (dev_ms * 1e-3) / 1e9
+        traffic, traffic_doc = measured_traffic()
+        engine = norm._get_backend_impl()
+        two_pass = bool(int(engine.tile_params(TILES)["n_candidates"].sum()) > 0 and int(engine._classic_left) == 0 and not os.environ.get("STAINX_MACENKO_CLASSIC"))
         line = {
             "metric": "megapixels/sec Macenko transform, 64x3x512x512 fp32; max-abs vs torch CPU",
             "value": round(value, 1), "unit": "megapixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Macenko reference-mode transform, 64x3x512x512 fp32 per GPU (BASELINE configs[1])",
-                       "tiles_per_gpu": TILES, "height": HEIGHT, "width": WIDTH, "parallelism": f"tiles sharded over {world} GPU(s), no collective"},
+                       "tiles_per_gpu": TILES, "height": HEIGHT, "width": WIDTH, "input_batches_rotated": n_batches,
+                       "parallelism": f"tiles sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(), "algorithmic_bytes_per_launch": pixels * BYTES_PER_PIXEL,
-                         "kernel": "all 7 launches of one sx_macenko_transform call (stats, plane, bracket<phi>, stain, bracket<conc>, scale, reconstruct)",
+                         "frac_of_copy_ceiling": round(achieved / COPY_CEILING_GBS, 4), "copy_ceiling": COPY_CEILING_GBS,
+                         "traffic": traffic, "traffic_source": (str(TRAFFIC_FILE.relative_to(ROOT)) + " (same kernel sources: " + source_hash() + ")") if traffic else None,
+                         "algorithmic_bytes_per_launch": pixels * BYTES_PER_PIXEL,
+                         "kernel": "all 4 launches of one sx_macenko_transform call in its two-pass form (prior, pass_a, estimate_stage, reconstruct)" if two_pass
+                                   else "all 7 launches of one sx_macenko_transform call in its four-pass form (stats, plane, bracket<phi>, stain, bracket<conc>, scale, reconstruct)",
                          "device_ms_per_call": round(dev_ms, 4), "device_ms_std": round(dev_std, 4), "device_ms_min": round(min(step_ms), 4),
                          "device_ms_median": round(sorted(step_ms)[len(step_ms) // 2], 4),
+                         "device_ms_hot": round(sum(hot_ms) / len(hot_ms), 4),
+                         "device_ms_hot_note": "the same call over ONE input buffer (201 MB: it stays in the 256 MiB Infinity Cache between calls), what the reference's harness would time",
                          "dominant_kernel": {"name": "reconstruct_kernel", "algorithmic_bytes": pixels * BYTES_PER_PIXEL,
-                                             "note": "the only launch that moves the full 24 B/px; its rocprofv3 average is in profiles/r01_final_macenko_cfg2_kernel_stats.csv"}},
+                                             "note": f"the only launch that moves the full 24 B/px; its rocprofv3 average is in {KERNEL_STATS}"}},
+            "kernel_source_hash": source_hash(),
         }
         if world == 1 and not args.no_cpu:
             he = norm._stain_matrix.cpu().numpy()
@@ -166,7 +273,7 @@ def main() -> None:
             # parity of the timed output against the oracle on the same sample (0-255 scale)
             from oracle import stain_oracle as so
 
-            want = so.macenko_transform(x_cpu[:2].numpy(), he, max_c)
+            want = so.macenko_transform(batches[last_batch][:2].cpu().numpy(), he, max_c)
             line["max_abs_vs_oracle_0_255"] = float((out[:2].cpu() - torch.from_numpy(want)).abs().max())
         sys.stdout.flush()
         os.dup2(real_stdout, 1)

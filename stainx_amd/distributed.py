@@ -23,10 +23,57 @@ stand-in provider in the tests.
 """
 from __future__ import annotations
 
+import os
 from typing import Any
 
 import torch
 import torch.distributed as dist
+
+# STAINX_FORCE_COLLECTIVES=1 (or force=True): a process group of ONE rank still goes through dist.all_reduce / all_gather, so that
+# the RCCL path can be exercised -- and timed -- on a one-GPU box (tests/test_distributed_gpu.py, bench.py --workload fit_transform_pooled).
+FORCE_COLLECTIVES = bool(os.environ.get("STAINX_FORCE_COLLECTIVES"))
+
+
+# bench.py --workload fit_transform_pooled: device time spent inside the collectives (HIP events around every dist call)
+_TIMED: list | None = None
+
+
+class collective_timer:
+    """``with collective_timer() as t: ...; t.ms()`` -- sum of the device time of every collective issued inside (synchronises)."""
+
+    def __enter__(self):
+        global _TIMED
+        _TIMED = []
+        return self
+
+    def __exit__(self, *exc):
+        global _TIMED
+        self._pairs, _TIMED = _TIMED, None
+        return False
+
+    def ms(self) -> float:
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self._pairs))
+
+    def count(self) -> int:
+        return len(self._pairs)
+
+
+def _timed(fn, *args, **kwargs):
+    if _TIMED is None or not torch.cuda.is_available():
+        return fn(*args, **kwargs)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = fn(*args, **kwargs)
+    b.record()
+    _TIMED.append((a, b))
+    return out
+
+
+def _skip_collective(size: int, force: bool | None) -> bool:
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return size == 1 and not (FORCE_COLLECTIVES if force is None else force)
 
 
 def world(group=None) -> tuple[int, int]:
@@ -43,24 +90,24 @@ def shard_bounds(n_items: int, rank: int, world_size: int) -> tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+def all_reduce_sum(t: torch.Tensor, group=None, force: bool | None = None) -> torch.Tensor:
     """In-place SUM over ranks.  RCCL reduces device tensors directly; gloo is staged through the host."""
     _, size = world(group)
-    if size == 1:
+    if _skip_collective(size, force):
         return t
     if t.is_cuda and dist.get_backend(group) != "nccl":
         host = t.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         t.copy_(host)
     else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _timed(dist.all_reduce, t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
-def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
+def all_gather_stack(t: torch.Tensor, group=None, force: bool | None = None) -> torch.Tensor:
     """Every rank's ``t`` (same shape everywhere) stacked along a new leading axis, in rank order."""
     _, size = world(group)
-    if size == 1:
+    if _skip_collective(size, force):
         return t.unsqueeze(0)
     if t.is_cuda and dist.get_backend(group) != "nccl":
         host = t.cpu()
@@ -68,8 +115,34 @@ def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
         dist.all_gather(parts, host, group=group)
         return torch.stack(parts).to(t.device)
     parts = [torch.empty_like(t) for _ in range(size)]
-    dist.all_gather(parts, t.contiguous(), group=group)
+    _timed(dist.all_gather, parts, t.contiguous(), group=group)
     return torch.stack(parts)
+
+
+def tiles_per_rank(n_local: int, device, group=None) -> list[int]:
+    """Every rank's tile count (one tiny all-gather).  Raises on EVERY rank if some rank holds no tile: that rank could not run
+    its local steps and the others would wait in the next collective until it times out."""
+    _, size = world(group)
+    if _skip_collective(size, None):
+        tiles = [int(n_local)]
+    else:
+        tiles = [int(v) for v in all_gather_stack(torch.tensor([int(n_local)], dtype=torch.int64, device=device), group).flatten().tolist()]
+    if min(tiles) <= 0:
+        raise ValueError(f"every rank needs at least one tile for a pooled statistic, got tiles per rank {tiles} (shard with shard_bounds over >= world_size tiles)")
+    return tiles
+
+
+def macenko_fit_transform_pooled(local_images: torch.Tensor, *, group=None, steps: Any | None = None, device=None, normalize_to_0_1: bool = False,
+                                 method: str = "brackets") -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``fit_transform`` of a batch sharded across ranks (BASELINE configs[3]; reference: base.py:51-61 on the pooled estimate of
+    torch_backend.py:463-519): ONE stain estimate over the union of every rank's tiles becomes the target, then every rank
+    transforms its own tiles to it -- the only exchanges are the fit's small statistics.  Returns ``(out, HE, maxC)``."""
+    if steps is None:
+        from stainx_amd.backends.torch_hip_backend import MacenkoHIP
+
+        steps = MacenkoHIP(device if device is not None else local_images.device)
+    he, max_c = macenko_fit_pooled(local_images, group=group, steps=steps, method=method)
+    return steps.transform(local_images, he, max_c, normalize_to_0_1=normalize_to_0_1), he, max_c
 
 
 def macenko_fit_pooled(local_images: torch.Tensor, *, group=None, steps: Any | None = None, device=None, method: str = "brackets") -> tuple[torch.Tensor, torch.Tensor]:
@@ -103,14 +176,14 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps):
     n, _, h, w = local_images.shape
     shape = (int(n), int(h), int(w))
     dev = steps.device if hasattr(steps, "device") else local_images.device
-    if size == 1:
-        tiles = [int(n)]
-    else:      # tiles per rank: the sample union and the pixel total need them (shapes only, no pixel data)
-        tiles = all_gather_stack(torch.tensor([n], dtype=torch.int64, device=dev), group).flatten().tolist()
+    tiles = tiles_per_rank(int(n), dev, group)      # the sample union and the pixel total need them (shapes only, no pixel data)
+    size = len(tiles)                                 # (1 when the collectives are skipped)
     n_all = int(sum(tiles)) * int(h) * int(w)
+    if n_all >= 1 << 32:
+        raise ValueError(f"a pooled fit over {n_all} pixels exceeds the 2^32 the native counters hold; fit on a subset of the tiles")
     moments, sample = steps.pfit_stats(local_images)
     moments = all_reduce_sum(moments, group)
-    if size == 1:
+    if _skip_collective(world(group)[1], None):
         union, sample_count = sample, steps.pfit_sample_count(int(n), int(h), int(w))
     else:
         samples = all_gather_stack(sample, group)                           # (world, 3, 4096)
@@ -140,6 +213,7 @@ def reinhard_transform_pooled(local_images: torch.Tensor, reference_mean, refere
         from stainx_amd.backends.torch_hip_backend import ReinhardHIP
 
         steps = ReinhardHIP(device if device is not None else local_images.device)
+    tiles_per_rank(int(local_images.shape[0]), local_images.device if local_images.is_cuda else (device or "cpu"), group)
     sums = all_reduce_sum(steps.local_sums(local_images), group)
     pixels = torch.tensor([local_images.shape[0] * local_images.shape[2] * local_images.shape[3]], dtype=torch.int64, device=sums.device)
     n_total = int(all_reduce_sum(pixels, group).item())
@@ -152,6 +226,7 @@ def hm_transform_pooled(local_images: torch.Tensor, reference_histogram, *, grou
         from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
 
         steps = HistogramMatchingHIP(device if device is not None else local_images.device, channel_axis=channel_axis)
+    tiles_per_rank(int(local_images.shape[0]), local_images.device if local_images.is_cuda else (device or "cpu"), group)
     counts = all_reduce_sum(steps.local_counts(local_images), group)
     n_total = int(counts[0].sum().item())
     return steps.apply_with_counts(local_images, counts, n_total, reference_histogram)

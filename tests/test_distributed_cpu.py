@@ -77,3 +77,61 @@ def test_two_rank_gloo_matches_single_process_oracle(tmp_path):
     np.testing.assert_array_equal(np.concatenate([r0["hm"], r1["hm"]]), want_hm)
     # and pooling matters: per-shard statistics give a different answer
     assert not np.array_equal(so.hm_transform(noise[:3], so.hm_fit(ref)), r0["hm"])
+
+
+def _empty_rank_worker(rank: int, world_size: int, port: int, out_dir: str):
+    from tests._numpy_steps import NumpyHMSteps, NumpyMacenkoBracketSteps
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        tiles = synth.he_batch(1, 32, 32, seed0=3)                       # one tile over two ranks: rank 1 gets nothing
+        lo, hi = sxd.shard_bounds(1, rank, world_size)
+        raised = []
+        for call in (lambda: sxd.macenko_fit_pooled(tiles[lo:hi], steps=NumpyMacenkoBracketSteps()),
+                     lambda: sxd.hm_transform_pooled(synth.noise_u8((1, 3, 16, 16), 1)[lo:hi], so.hm_fit(synth.noise_u8((1, 3, 16, 16), 2).numpy()), steps=NumpyHMSteps())):
+            try:
+                call()
+                raised.append(False)
+            except ValueError as exc:
+                raised.append("at least one tile" in str(exc))
+        np.savez(os.path.join(out_dir, f"empty{rank}.npz"), raised=np.array(raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_without_tiles_raises_on_every_rank_instead_of_hanging(tmp_path):
+    mp.spawn(_empty_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in (0, 1):
+        assert np.load(tmp_path / f"empty{rank}.npz")["raised"].all(), rank
+
+
+def _forced_worker(rank: int, world_size: int, port: int, out_dir: str):
+    from tests._numpy_steps import NumpyMacenkoBracketSteps
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        calls = {"n": 0}
+        real = dist.all_reduce
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return real(*a, **k)
+
+        dist.all_reduce = counting
+        tiles = synth.he_batch(3, 48, 48, seed0=9)
+        plain = sxd.macenko_fit_pooled(tiles, steps=NumpyMacenkoBracketSteps())
+        assert calls["n"] == 0                                            # one rank: the collectives are skipped ...
+        sxd.FORCE_COLLECTIVES = True
+        forced = sxd.macenko_fit_pooled(tiles, steps=NumpyMacenkoBracketSteps())
+        assert calls["n"] >= 3                                            # ... unless forced (what the one-GPU RCCL test and bench mode use)
+        np.savez(os.path.join(out_dir, "forced.npz"), same=bool(torch.equal(plain[0], forced[0]) and torch.equal(plain[1], forced[1])))
+    finally:
+        sxd.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_size_one(tmp_path):
+    mp.spawn(_forced_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert bool(np.load(tmp_path / "forced.npz")["same"])

@@ -112,3 +112,65 @@ def test_two_ranks_on_one_gpu(tmp_path, golden):
     np.testing.assert_array_equal(np.concatenate([r0["hm"], r1["hm"]]), want_hm)
     want_rein = so.reinhard_transform(noise, *so.reinhard_fit(ref))
     assert np.abs(np.concatenate([r0["rein"], r1["rein"]]).astype(int) - want_rein.astype(int)).max() <= 1
+
+
+def _rccl_worker(rank: int, world_size: int, port: int, out_dir: str):
+    """ONE rank, backend nccl (= RCCL on ROCm), collectives forced: every all_reduce / all_gather of the pooled paths really runs
+    through RCCL -- fp64 moments, int64 counts, int32 candidate keys, fp32 samples."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), STAINX_FORCE_COLLECTIVES="1")
+    import importlib
+
+    importlib.reload(sxd)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+    try:
+        calls = {"all_reduce": 0, "all_gather": 0}
+        real_ar, real_ag = dist.all_reduce, dist.all_gather
+
+        def count_ar(*a, **k):
+            calls["all_reduce"] += 1
+            return real_ar(*a, **k)
+
+        def count_ag(*a, **k):
+            calls["all_gather"] += 1
+            return real_ag(*a, **k)
+
+        dist.all_reduce, dist.all_gather = count_ar, count_ag
+        from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP, MacenkoHIP, ReinhardHIP
+
+        tiles = synth.he_batch(8, 128, 128).to(dev)
+        he, max_c = sxd.macenko_fit_pooled(tiles)
+        he_r, max_c_r = sxd.macenko_fit_pooled(tiles, method="radix")
+        out, he_t, max_c_t = sxd.macenko_fit_transform_pooled(synth.as_dtype(synth.he_batch(8, 128, 128), torch.float32).to(dev))
+        noise = synth.noise_u8((3, 3, 67, 45), 43).to(dev)
+        ref = synth.noise_u8((1, 3, 67, 45), 42).to(dev)
+        rb = ReinhardHIP(dev)
+        mean, std = rb.compute_reference_mean_std(ref)
+        rein = sxd.reinhard_transform_pooled(noise, mean, std)
+        hb = HistogramMatchingHIP(dev)
+        hists = hb.compute_reference_histograms(ref)
+        hm = sxd.hm_transform_pooled(noise, hists)
+        torch.cuda.synchronize()
+        fused = MacenkoHIP(dev)
+        he_f, mc_f = fused.compute_reference_stain_matrix(synth.as_dtype(synth.he_batch(8, 128, 128), torch.float32).to(dev))
+        out_f = fused.transform(synth.as_dtype(synth.he_batch(8, 128, 128), torch.float32).to(dev), he_f, mc_f)
+        np.savez(os.path.join(out_dir, "rccl.npz"), he=he.cpu().numpy(), max_c=max_c.cpu().numpy(), he_r=he_r.cpu().numpy(), max_c_r=max_c_r.cpu().numpy(),
+                 out_equal=bool(torch.equal(out, out_f)) and bool(torch.equal(he_t, he_f)) and bool(torch.equal(max_c_t, mc_f)),
+                 rein_equal=bool(torch.equal(rein, rb.transform(noise, mean, std))), hm_equal=bool(torch.equal(hm, hb.transform(noise, hists))),
+                 all_reduce=calls["all_reduce"], all_gather=calls["all_gather"], backend=dist.get_backend())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_runs_every_collective(tmp_path, golden):
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    g = golden("g3_macenko_fit.npz")
+    assert str(r["backend"]) == "nccl"
+    assert int(r["all_reduce"]) >= 1 + 2 + 9 + 3 + 2 and int(r["all_gather"]) >= 2 * (1 + 1 + 4)      # bracket fit twice (fit, fit_transform), radix fit, Reinhard, HM
+    np.testing.assert_allclose(r["he"], g["pooled8x128_he"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(r["max_c"], g["pooled8x128_max_c"], rtol=1e-4, atol=0)
+    np.testing.assert_array_equal(r["he"], r["he_r"])
+    np.testing.assert_array_equal(r["max_c"], r["max_c_r"])
+    assert bool(r["out_equal"]) and bool(r["rein_equal"]) and bool(r["hm_equal"])
