@@ -292,6 +292,24 @@ def g8_transform_module():
     print("g8 done")
 
 
+def g10_config5_tile_shape():
+    """BASELINE configs[4] at its tile shape: StainNormalizerTransform(macenko, reference) on 2 x 3 x 224 x 224 bf16 (the module's
+    defaults: normalize_to_0_1), and the channels-last / half-precision-output pipeline inputs the extensions are checked with."""
+    ref = synth.reference_tile(224, 224)
+    src = synth.he_batch(2, 224, 224, seed0=500, scale_step=0.03)
+    t = stainx.StainNormalizerTransform(method="macenko", mode="reference", reference=synth.as_dtype(ref, torch.bfloat16), device="cpu", backend="torch")
+    blob = {"reference_bf16": to_np(t(synth.as_dtype(src, torch.bfloat16))), "src_sha256": np.frombuffer(sha(src).encode(), dtype=np.uint8),
+            "stain_matrix": to_np(t.normalizer._stain_matrix.float()), "target_max_conc": to_np(t.normalizer._target_max_conc.float())}
+    # uint8 tiles through the plain normaliser (0-255 uint8 out, and float32 in [0, 1]): what the NHWC / bf16-output extensions must equal
+    n8 = stainx.Macenko(device="cpu", backend="torch").fit(ref)
+    blob["u8_out"] = to_np(n8.transform(src))
+    n01 = stainx.Macenko(device="cpu", backend="torch", normalize_to_0_1=True).fit(ref)
+    blob["u8_out01"] = to_np(n01.transform(src))
+    blob["u8_stain_matrix"], blob["u8_target_max_conc"] = to_np(n8._stain_matrix.float()), to_np(n8._target_max_conc.float())
+    np.savez_compressed(HERE / "g10_config5_shape.npz", **blob)
+    print("g10 done")
+
+
 def g9_histogram_matching_random():
     """80 random small cases (uniform noise, odd sizes, four dtypes): the reference's float32 LUT arithmetic depends on
     the last bit of a `sum()` whose order is ATen's vectorised one -- these cases pin it (a restatement that adds the 256
@@ -309,8 +327,9 @@ def g9_histogram_matching_random():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
     table = {"g1": g1_macenko_small, "g2": g2_macenko_config2, "g3": g3_macenko_fit, "g4": g4_reinhard,
-             "g5": g5_histogram_matching, "g6": g6_edge_cases, "g8": g8_transform_module, "g9": g9_histogram_matching_random}
+             "g5": g5_histogram_matching, "g6": g6_edge_cases, "g8": g8_transform_module, "g9": g9_histogram_matching_random,
+             "g10": g10_config5_tile_shape}
     for w in which:
         table[w]()
