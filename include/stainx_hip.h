@@ -42,8 +42,10 @@ typedef enum {
 
 /* flags for sx_macenko_transform */
 #define SX_MACENKO_NORMALIZE_0_1 1u /* fuse `result / 255.0` (normalizers/_template.py:111-112); u8 input -> f32 output */
-#define SX_MACENKO_FAST 4u          /* Macenko(precision="fast") (normalizers/macenko.py:35-44, a relaxed-accuracy path in the reference too): the
-                                      percentiles of a 4096-pixel sample of each tile stand in for the exact ones -- two passes instead of four */
+#define SX_MACENKO_SAMPLED 4u       /* an APPROXIMATION (not a parity path, not the reference's precision="fast"): the percentiles of a 4096-pixel
+                                      sample of each tile stand in for the exact ones -- moments pass, one per-tile stage, reconstruct.  Mean
+                                      error ~0.5, worst ~5 grey levels on H&E tiles.  Macenko(precision="sampled") in the Python host; the
+                                      reference's precision="fast" (fp16 tensors, exact percentiles, MAE ~0.05) is served by the exact path. */
 #define SX_MACENKO_OUT_BF16 32u      /* uint8 input only: the result is written as bfloat16 -- bit for bit `transform(x).to(bfloat16)`, with
                                        SX_MACENKO_NORMALIZE_0_1 `transform(x, normalize_to_0_1).to(bfloat16)` -- so a uint8 tile from the decoder
                                        becomes a model's bf16 input with 3 bytes read and 6 written per pixel (an extension: SURVEY.md 8f-2) */

@@ -163,6 +163,47 @@ def macenko_transform(images: np.ndarray, stain_matrix: np.ndarray, target_max_c
     return (result, params) if return_params else result
 
 
+def macenko_transform_fast(images: np.ndarray, stain_matrix: np.ndarray, target_max_conc: np.ndarray, *, signs=None) -> np.ndarray:
+    """The reference's ``precision="fast"`` native path (src/stainx_cuda_torch/csrc/macenko.cu:116-191), restated: the same
+    algorithm with EXACT nearest-rank percentiles, but the big per-pixel tensors in float16 -- optical densities and plane
+    vectors rounded to float16 before the projection (:135-137), angles in float16 (:140), concentrations rounded to float16
+    for the percentile and the rescale (:181-191), stain matrix in float16 for the reconstruction (:196-198); covariance and
+    eigenvectors float32 (:124), the 2x2 normal equations float32 (:160-176).  cuBLAS accumulates the float16 products in
+    float32 and rounds once; numpy's float16 matmul is emulated the same way here (float32 product of float16 operands,
+    rounded to float16).  Published accuracy of that mode: MAE ~0.05 grey levels against torchstain (docs/benchmarks.md,
+    BASELINE.md section 1); this restatement is what tests/test_precision_modes_gpu.py holds ``precision="fast"`` to."""
+    f16 = np.float16
+    sm = np.asarray(stain_matrix, dtype=F32)
+    tmc = np.asarray(target_max_conc, dtype=F32).reshape(-1)
+    n_img, _, height, width = images.shape
+    od_all = optical_density(to_unit_float(images))                       # float32 (:99)
+    out = np.empty((n_img, 3, height, width), dtype=F32)
+    for n in range(n_img):
+        od = od_all[n].reshape(3, -1)                                     # (3, P)
+        rows = od.T                                                       # (P, 3)
+        keep = rows.min(axis=1) >= BETA                                   # :105-106 (float32 mask)
+        if keep.sum() < 3:
+            keep = np.ones_like(keep)
+        vecs = plane_vectors(od_covariance(rows[keep]), signs)            # float32 covariance + eigh (:124)
+        proj = (rows.astype(f16).astype(F32) @ vecs.astype(f16).astype(F32)).astype(f16)      # fp16 bmm (:135-137)
+        phi = np.arctan2(proj[:, 1].astype(F32), proj[:, 0].astype(F32)).astype(f16)          # :140
+        phi_kept = phi[keep].astype(F32)
+        phi_lo, phi_hi = nearest_rank(phi_kept, ALPHA), nearest_rank(phi_kept, 100.0 - ALPHA)   # exact ranks of the fp16 values (:144-148)
+        he = stain_vectors_from_angles(vecs, phi_lo, phi_hi)              # float32 (:151-161)
+        a2 = (he.T @ he).astype(F32)                                      # 2x2 normal equations, float32 (:165-176)
+        rhs = (he.T @ od).astype(F32)
+        det = a2[0, 0] * a2[1, 1] - a2[0, 1] * a2[0, 1]
+        c0 = (a2[1, 1] / det) * rhs[0] + (-a2[0, 1] / det) * rhs[1]
+        c1 = (-a2[0, 1] / det) * rhs[0] + (a2[0, 0] / det) * rhs[1]
+        c0h, c1h = c0.astype(f16), c1.astype(f16)                         # :181-183
+        max_c = np.array([nearest_rank(c0h.astype(F32), 99), nearest_rank(c1h.astype(F32), 99)], dtype=F32)
+        scale = (tmc / max_c).astype(f16)                                 # :191-192
+        cn = np.stack([(c0h * scale[0]).astype(f16), (c1h * scale[1]).astype(f16)])             # (2, P) float16
+        od_new = (sm.astype(f16).astype(F32) @ cn.astype(F32)).astype(f16).astype(F32)          # fp16 matmul (:196-198)
+        out[n] = np.clip(IO * np.exp(-od_new), F32(0), F32(255)).reshape(3, height, width)
+    return restore_dtype(out, images.dtype, in_0_255=True)
+
+
 def macenko_fit(images: np.ndarray, *, signs=None) -> tuple[np.ndarray, np.ndarray]:
     """``compute_reference_stain_matrix_torch`` (torch_backend.py:463-519): pooled over the batch, no <3 fallback."""
     if images.ndim != 4 or images.shape[1] != 3:

@@ -19,7 +19,7 @@ LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libstainx_hip.so"
 SX_OK, SX_ERR_BAD_ARG, SX_ERR_DTYPE, SX_ERR_WORKSPACE, SX_ERR_LAUNCH = range(5)
 MACENKO_NORMALIZE_0_1 = 1
 MACENKO_CHANNELS_LAST = 2
-MACENKO_FAST = 4
+MACENKO_SAMPLED = 4
 MACENKO_NO_TIE_SHORTCUT = 8
 MACENKO_CLASSIC = 16
 MACENKO_OUT_BF16 = 32

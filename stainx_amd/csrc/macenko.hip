@@ -1048,6 +1048,14 @@ __device__ __forceinline__ GroupPixels group_pixels(const Geometry& g, int group
 
 // Offset of sample j inside its stride-long cell: top `shift` bits of a multiplicative hash of j.
 __device__ __forceinline__ uint32_t sample_offset(uint32_t j, int shift) { return shift ? (j * 0x9E3779B1u) >> (32 - shift) : 0u; }
+// The same, kept inside a group of `count` pixels: the LAST cell may be partial (300 x 300 = 90000 pixels, stride 32: cell 2812 is
+// 16 pixels long) and a hashed offset beyond its end would name a pixel that does not exist -- that sample was never written
+// and the stages read whatever the workspace held (with the sampled percentiles of precision="sampled" that reached the output).
+__device__ __forceinline__ uint32_t sample_offset_in(uint32_t j, int shift, uint32_t count) {
+    const uint32_t off = sample_offset(j, shift), cell_begin = j << shift;
+    const uint32_t cell_len = count - cell_begin;      // (callers only ask for cells that begin inside the group)
+    return (shift && cell_len < (1u << shift)) ? off % cell_len : off;
+}
 
 // ------------------------------------------------------------------------------------------------
 // streaming stage S1: raw moments of the OD vectors of one work item (+ the sample's OD on the way)
@@ -1117,6 +1125,7 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     float* sample_out = ws.sample_od + (size_t)group * 3 * kSample;
     const uint32_t group_offset = g.pooled ? (uint32_t)(tile * g.pixels) : 0u;      // position of this tile inside its group (< 2^32)
     const uint32_t sample_count = (uint32_t)g.sample_count;
+    const uint32_t group_count = (uint32_t)(g.pooled ? g.n_tiles * g.pixels : g.pixels);      // pixels of the group the sample is drawn from (< 2^32)
     const uint32_t mask = (uint32_t)g.sample_stride - 1u;          // stride is a power of two
     const int shift = 31 - __clz(g.sample_stride);
     constexpr int kLog2V = V == 16 ? 4 : V == 8 ? 3 : V == 4 ? 2 : V == 2 ? 1 : 0;
@@ -1140,7 +1149,7 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
             load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p, u);
             // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
             // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
-            const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset(j, shift);
+            const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset_in(j, shift, group_count);
             if (by_pack && (((gpos & mask) ^ off) >> kLog2V) == 0u && j < sample_count) {
                 float raw[3] = {u[0][0], u[1][0], u[2][0]};
 #pragma unroll
@@ -1159,7 +1168,7 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
                 for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u[c][i], tb);
                 if (!by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
                     const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
-                    if ((pos & mask) == sample_offset(jj, shift) && jj < sample_count) {
+                    if ((pos & mask) == sample_offset_in(jj, shift, group_count) && jj < sample_count) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + jj], od[c]);
                     }
@@ -2706,7 +2715,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
         return fail(SX_ERR_BAD_ARG, "SX_MACENKO_OUT_BF16 / SX_MACENKO_OUT_F16: uint8 input only, one of the two");
     Geometry g = make_geometry(n, h * w, 0);
     g.interleaved = (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0;
-    g.fast = (flags & SX_MACENKO_FAST) ? 1 : 0;
+    g.fast = (flags & SX_MACENKO_SAMPLED) ? 1 : 0;
     g.no_tie = (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0;
     g.out_code = (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0);
     g.spec_fail = (flags & SX_MACENKO_SPEC_FAIL) ? 1 : 0;

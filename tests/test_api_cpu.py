@@ -57,6 +57,7 @@ def test_backend_ids():
     with pytest.raises(ValueError, match="precision must be"):
         Macenko(precision="ultra")
     assert Macenko(device="cuda", precision="fast").engine_options() == {"precision": "fast"}
+    assert Macenko(device="cuda", precision="sampled").engine_options() == {"precision": "sampled"}
 
 
 def test_no_cpu_fallback():

@@ -331,29 +331,6 @@ def test_big_batch_equals_its_pieces(dev):
         assert torch.equal(params["he"][lo:hi], p["he"]) and torch.equal(params["max_c"][lo:hi], p["max_c"])
 
 
-def test_precision_fast_is_a_sampled_estimate(dev):
-    """Macenko(precision="fast"): per-tile percentiles from the 4096-pixel sample (two passes instead of four).  Not a
-    parity path -- the reference's own fast mode is a relaxed-accuracy one too -- so the check is statistical: close to
-    the exact transform (mean abs error below one grey level over the batch, 2.5 on the worst tile -- measured 0.5 / 1.5 on
-    64 tiles of 512x512), same shape/dtype, deterministic."""
-    from stainx_amd import Macenko
-
-    ref = synth.reference_tile(128, 128).to(dev)
-    x = synth.as_dtype(synth.he_batch(6, 256, 256, seed0=5100), torch.float32).to(dev)
-    exact = Macenko(device=dev).fit(ref).transform(x)
-    fast_norm = Macenko(device=dev, precision="fast").fit(ref)
-    fast = fast_norm.transform(x)
-    assert fast.shape == exact.shape and fast.dtype == exact.dtype
-    err = (fast - exact).abs().reshape(6, -1)
-    assert float(err.mean()) < 1.0 and float(err.mean(1).max()) < 2.5, err.mean(1)
-    assert float(err.max()) < 15.0
-    assert torch.equal(fast, fast_norm.transform(x))
-    for dt in ("u8", "bf16"):
-        xi = synth.as_dtype(synth.he_batch(2, 64, 96, seed0=5200), TORCH_DTYPES[dt]).to(dev)
-        out = fast_norm.transform(xi)
-        assert out.dtype == xi.dtype and out.shape == xi.shape
-
-
 def _sparse_tile(tile_u8: torch.Tensor, side: int, rng: np.random.Generator) -> torch.Tensor:
     """White background (optical density below the filter threshold in every channel) with a side x side patch of tissue."""
     out = torch.from_numpy(rng.integers(236, 250, size=tuple(tile_u8.shape), dtype=np.uint8))

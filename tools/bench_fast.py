@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Macenko(precision="fast") against the exact path: time and error on the config-2 batch (64x3x512x512 fp32)."""
+"""Macenko(precision="sampled") against the exact path: time and error on the config-2 batch (64x3x512x512 fp32)."""
 import json
 import sys
 from pathlib import Path
@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 ref = synth.reference_tile(512, 512).to(dev)
 x = synth.as_dtype(synth.he_batch(64, 512, 512), torch.float32).to(dev)
 res = {}
-for precision in ("stable", "fast"):
+for precision in ("stable", "sampled"):
     norm = Macenko(device=dev, precision=precision).fit(ref)
     for _ in range(10):
         out = norm.transform(x)
@@ -25,7 +25,7 @@ for precision in ("stable", "fast"):
     e1.record()
     torch.cuda.synchronize()
     res[precision] = (out, e0.elapsed_time(e1) / 50)
-d = (res["fast"][0] - res["stable"][0]).abs()
-print(json.dumps({"stable_ms": round(res["stable"][1], 4), "fast_ms": round(res["fast"][1], 4), "fast_megapixels_per_s": round(64 * 512 * 512 / 1e3 / res["fast"][1], 1),
+d = (res["sampled"][0] - res["stable"][0]).abs()
+print(json.dumps({"stable_ms": round(res["stable"][1], 4), "fast_ms": round(res["sampled"][1], 4), "fast_megapixels_per_s": round(64 * 512 * 512 / 1e3 / res["sampled"][1], 1),
                   "fast_vs_stable_max_abs_0_255": round(float(d.max()), 3), "mean_abs_0_255": round(float(d.mean()), 4),
                   "per_tile_mean_abs_max": round(float(d.reshape(64, -1).mean(1).max()), 4)}))
