@@ -26,6 +26,13 @@ def _same_layout(a: int, b: int) -> bool:
     return (a in _CHANNELS_FIRST) == (b in _CHANNELS_FIRST)
 
 
+def _resolved(device) -> torch.device:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 class StainNormalizerTransform(nn.Module):
     """Apply a stain normaliser to CHW / NCHW (histogram matching: also HWC / NHWC) tensors.
 
@@ -107,8 +114,12 @@ class StainNormalizerTransform(nn.Module):
         device = torch.device(device)
         if self._requested_backend in _GPU_BACKENDS and device.type != "cuda":
             raise ValueError(f"backend='{self._requested_backend}' requires CUDA tensors when device=None; got {device}.")
-        current = torch.device(self.normalizer.device)
-        if current.type == device.type and (current.index is None or device.index is None or current.index == device.index):
+        # compare RESOLVED devices: an index-less "cuda" names the current device (that is where the engine pinned itself), and a
+        # tensor on another GPU must move the normaliser there instead of being copied to the engine's GPU behind the caller's back
+        engine = self.normalizer._engine
+        current = _resolved(engine.device if engine is not None else self.normalizer.device)
+        device = _resolved(device)
+        if current == device:
             return
         self.normalizer.device = device
         self.normalizer._engine = None

@@ -150,3 +150,15 @@ def test_dataloader_style_pipeline(dev, reference):
         assert out.dtype == torch.bfloat16 and out.shape == batch.shape
         want = torch.from_numpy(so.macenko_transform(batch.float().numpy(), he, mc)).to(torch.bfloat16) / 255.0
         assert (out.cpu().float() - want.float()).abs().max().item() <= 2.0 ** -8
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_module_follows_its_input_to_another_gpu(reference):
+    """device=None: the result lives where the input lives, also when the normaliser was built index-less ("cuda") while GPU 0 was
+    current and the batch arrives on GPU 1 ('cuda' and 'cuda:1' used to count as the same device)."""
+    t = StainNormalizerTransform(method="macenko", mode="reference", reference=synth.as_dtype(reference, torch.float32).to("cuda:0"))
+    x = synth.as_dtype(synth.he_batch(2, 56, 56, seed0=41), torch.float32)
+    out0 = t(x.to("cuda:0"))
+    out1 = t(x.to("cuda:1"))
+    assert out0.device == torch.device("cuda:0") and out1.device == torch.device("cuda:1")
+    assert torch.equal(out0.cpu(), out1.cpu())
