@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const T* __restrict__ i
                 res.v[i] = lut[c][grey_level<T>(pk.v[i])];
                 if (lay.channels_last) c = c == 2 ? 0 : c + 1;
             }
-            *reinterpret_cast<Pack<T, V>*>(out + e) = res;
+            store_pack_stream<T, V>(out + e, res.v);      // non-temporal: written once, not read again by this library
         } else {
             out[e] = lut[lay.channel_of(e)][grey_level<T>(images[e])];
         }

@@ -239,8 +239,10 @@ __global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restri
                     res[c][i] = Elem<T>::store(back[c]);
             }
         }
+        // (non-temporal: the output is not read again by this library and leaves no dirty lines for the next reader to wait on --
+        // the same change took 10 us off the Macenko transform)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) store_pack<T, V>(dst + c * g.pixels + p, res[c]);
+        for (int c = 0; c < 3; ++c) store_pack_stream<T, V>(dst + c * g.pixels + p, res[c]);
     }
 }
 
