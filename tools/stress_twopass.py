@@ -30,7 +30,7 @@ for case in range(cases):
     x = synth.as_dtype(u8, dt).to(dev)
     if last:
         x = x.permute(0, 2, 3, 1).contiguous()
-    two = be.transform(x, sm, tmc, normalize_to_0_1=unit, channels_last=last)
+    two = be.transform(x, sm, tmc, normalize_to_0_1=unit, channels_last=last, _extra_flags=_native.MACENKO_TWO_PASS)
     p2 = be.tile_params(n)
     one = be.transform(x, sm, tmc, normalize_to_0_1=unit, channels_last=last, _extra_flags=_native.MACENKO_CLASSIC)
     p1 = be.tile_params(n)
