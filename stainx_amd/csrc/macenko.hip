@@ -78,6 +78,7 @@ struct alignas(256) GroupState {
     uint32_t fell_back;           // bit s: slot s used the whole-group radix select; bit 4+s: candidate radix select
     uint32_t spec;                // two-pass transform (macenko_twopass.hpp): kSpecSlow | kSpecHazard
     unsigned long long phi_pub[2];      // two-pass transform: {tag, angle key} granules the two stage workgroups of a tile hand each other
+    uint32_t over_count[kSlots];  // two-pass transform: candidates of the tile that did not fit their wave's segment (overflow area fill)
     uint32_t slow_slots;          // two-pass transform, tile 0 only: selections of the whole batch that left the speculative path (telemetry)
     unsigned long long stamp[16]; // diagnostic: wall_clock64() at stage boundaries of the per-tile stages
 };
@@ -104,6 +105,7 @@ struct Geometry {
     unsigned prior_step_q16;      // two-pass: sectors per sample cell, 16.16 fixed point
     uint32_t cap2;                // two-pass: candidate records per tile and slot
     uint32_t seg_cap;             // two-pass: ... of which every wave of pass A owns this many (its segment)
+    uint32_t over_cap;            // two-pass: ... and the tile's overflow area behind the segments holds this many
     int n_seg;                    // two-pass: segments per tile = waves of pass A per tile
     int spec_fail;                // diagnostic (SX_MACENKO_SPEC_FAIL): treat every speculation as failed -> the slow exact path
 };
@@ -171,7 +173,15 @@ static size_t cand_words(int64_t n_tiles, int64_t pixels) {
 // detected and sends the slot to the slow path), and whether a tile size takes that form at all.
 constexpr int kLdsKeys = 16384;        // candidate keys of a slot the stages keep in LDS; the rest spill to the classic candidate area
 constexpr size_t kPriorRecordBytes = 384;
-static uint32_t cap2_for(int64_t pixels) { return (uint32_t)std::min<int64_t>(std::max<int64_t>(pixels / 4, 8192), 262144); }
+// per tile and slot: one segment per wave of pass A (an eighth of the wave's pixels, at least 128), and an overflow area of half
+// the segments' total behind them; cap2 is the stride of the three planes of a slot's arrays
+static int two_pass_segments(int64_t pixels) { return (int)((pixels + kChunk - 1) / kChunk) * (kStreamThreads / kWave); }
+static uint32_t seg_cap_for(int64_t pixels) {
+    const int n_seg = two_pass_segments(pixels);
+    return (uint32_t)std::max<int64_t>(std::min<int64_t>(std::max<int64_t>(pixels / 8, 8192), 131072) / n_seg, 128);
+}
+static uint32_t over_cap_for(int64_t pixels) { return (uint32_t)(((int64_t)two_pass_segments(pixels) * seg_cap_for(pixels) / 2 + 255) / 256 * 256); }
+static uint32_t cap2_for(int64_t pixels) { return (uint32_t)((int64_t)two_pass_segments(pixels) * seg_cap_for(pixels)) + over_cap_for(pixels); }
 static size_t key_spill_words(int64_t pixels) { return cap2_for(pixels) > (uint32_t)kLdsKeys ? (size_t)cap2_for(pixels) - kLdsKeys : 0; }      // keys of a slot beyond the stages' LDS array
 static bool two_pass_size(int64_t pixels) { return pixels >= 256 && pixels <= 64ll * kChunk; }      // (at most 256 waves of pass A per tile)
 
@@ -2470,8 +2480,9 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     set_sampling(g);
     if (g.two_pass) {
         g.cap2 = cap2_for(g.pixels);
-        g.n_seg = g.blocks_per_tile * (kStreamThreads / kWave);
-        g.seg_cap = g.cap2 / (uint32_t)g.n_seg;
+        g.n_seg = two_pass_segments(g.pixels);
+        g.seg_cap = seg_cap_for(g.pixels);
+        g.over_cap = over_cap_for(g.pixels);
         const int64_t n_sectors = g.pixels / 16;
         g.prior_units = (int)std::min<int64_t>(std::max<int64_t>(n_sectors / 4, std::min<int64_t>(n_sectors, 64)), kPriorUnitsMax);
         g.prior_step_q16 = (unsigned)((n_sectors << 16) / g.prior_units);

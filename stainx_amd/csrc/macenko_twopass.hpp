@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         put(&st.ncand[tid], 0u);
         put(&st.below[tid], 0u);
         put(&st.ncand_seen[tid], 0u);
+        put(&st.over_count[tid], 0u);
     }
     if (tid < 2) put(&st.phi_pub[tid], 0ull);
     if (tile == 0 && tid == 0) put(&st.slow_slots, 0u);      // (tile 0's word counts for the batch)
@@ -441,8 +442,11 @@ template <int TPB> struct PassAScratch {
 // bit s of its flag word is set).  Every wave of a tile owns entries [k seg_cap, (k+1) seg_cap) of each slot, k = 4 * work
 // item + wave: no reservation, no atomic, nothing another wave waits for -- with a counter shared by the tile, a flush in
 // the middle of the pixel loop cost four returning atomics one after the other, ~10 us per wave.  `have[s]` counts what the
-// wave has produced so far (it may pass seg_cap: the stage sees that and takes the slow path for the slot).
-__device__ __forceinline__ void write_records(const uint4* __restrict__ queue, uint32_t n, uint32_t (&have)[kSlots], float* __restrict__ cand_tile, uint32_t cap2, uint32_t seg_base, uint32_t seg_cap) {
+// wave has produced so far.  What does not fit the segment (tissue concentrated in a few work items: a tile that is 90 %
+// background has all its candidates in two of them) goes to the tile's OVERFLOW area behind the segments, reserved with one
+// atomic per flush and slot -- the rare path.
+__device__ __forceinline__ void write_records(const uint4* __restrict__ queue, uint32_t n, uint32_t (&have)[kSlots], float* __restrict__ cand_tile, const Geometry& g, uint32_t seg_base, uint32_t* __restrict__ over_count) {
+    const uint32_t cap2 = g.cap2, seg_cap = g.seg_cap, over_base = (uint32_t)g.n_seg * g.seg_cap;
     for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
         const uint32_t i = i0 + lane_id();
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
@@ -451,16 +455,27 @@ __device__ __forceinline__ void write_records(const uint4* __restrict__ queue, u
         for (int s = 0; s < kSlots; ++s) {
             const bool has = ((rec.w >> s) & 1u) != 0;
             const uint64_t mask = __builtin_amdgcn_ballot_w64(has);
-            if (has) {
-                const uint32_t at = have[s] + rank_in_mask(mask);
-                if (at < seg_cap) {
-                    float* dst = cand_tile + (size_t)s * 3 * cap2 + seg_base + at;
-                    put(&dst[0], __uint_as_float(rec.x));
-                    put(&dst[cap2], __uint_as_float(rec.y));
-                    put(&dst[2 * (size_t)cap2], __uint_as_float(rec.z));
+            const uint32_t count = (uint32_t)__popcll(mask), at = have[s] + rank_in_mask(mask);
+            uint32_t idx = seg_base + at;
+            bool store = has;
+            if (__builtin_expect(have[s] + count > seg_cap, 0)) {      // wave-uniform: some of these do not fit the segment any more
+                const uint64_t spilled = __builtin_amdgcn_ballot_w64(has && at >= seg_cap);
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(&over_count[s], (uint32_t)__popcll(spilled));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (has && at >= seg_cap) {
+                    const uint32_t o = base + rank_in_mask(spilled);
+                    idx = over_base + o;
+                    store = o < g.over_cap;
                 }
             }
-            have[s] += (uint32_t)__popcll(mask);
+            if (store) {
+                float* dst = cand_tile + (size_t)s * 3 * cap2 + idx;
+                put(&dst[0], __uint_as_float(rec.x));
+                put(&dst[cap2], __uint_as_float(rec.y));
+                put(&dst[2 * (size_t)cap2], __uint_as_float(rec.z));
+            }
+            have[s] += count;
         }
     }
 }
@@ -505,7 +520,7 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
     float* cand_tile = ws.cand_od + (size_t)tile * kSlots * 3 * g.cap2;
     const uint32_t seg = (uint32_t)chunk_id * (TPB / kWave) + (uint32_t)wave, seg_base = seg * g.seg_cap;
     auto flush = [&]() {
-        write_records(queue, n_q, have, cand_tile, g.cap2, seg_base, g.seg_cap);
+        write_records(queue, n_q, have, cand_tile, g, seg_base, st.over_count);
         n_q = 0;
     };
 
@@ -675,23 +690,23 @@ struct alignas(16) SlotScratch {
     uint32_t lo, hi, n_list, bin, rank_in_bin, result, range_first, range_last, bin_count;
     int ok, use_all;
     unsigned long long n_sel;
-    uint32_t seg_prefix[kMaxSegments + 1], seg_total, seg_overflow;
+    uint32_t seg_prefix[kMaxSegments + 1], seg_total, seg_overflow, over_n;
     uint32_t own_key;
     int partner_ok;
 };
 
-// The slot's candidates lie in one segment per wave of pass A: prefix sums of the segment fills (one wave, four segments per
-// lane), so that candidate i of the slot is entry i - prefix[k] of segment k.  Needs a barrier before the prefix is used.
+// The slot's candidates lie in one segment per wave of pass A (+ the tile's overflow area): prefix sums of the segment fills
+// (one wave, four segments per lane), so that candidate i of the slot is entry i - prefix[k] of segment k; the overflow entries
+// follow as candidates prefix[n_seg] ... .  Needs a barrier before the prefix is used.
 __device__ __forceinline__ void segment_prefix(SlotScratch* sh, const Geometry& g, const Workspace& ws, int tile, int slot) {
     if (threadIdx.x < kWave) {
         const uint32_t* counts = ws.seg_count + ((size_t)tile * kSlots + slot) * g.n_seg;
-        uint32_t c[4], sum = 0, raw = 0, over = 0;
+        uint32_t c[4], sum = 0, raw = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = 4 * (int)threadIdx.x + u;
             const uint32_t v = k < g.n_seg ? get(&counts[k]) : 0u;
             raw += v;
-            over |= v > g.seg_cap ? 1u : 0u;
             c[u] = min(v, g.seg_cap);
             sum += c[u];
         }
@@ -704,14 +719,16 @@ __device__ __forceinline__ void segment_prefix(SlotScratch* sh, const Geometry& 
             run += c[u];
         }
         const uint32_t total_raw = wave_total_u32(raw);
-        const uint64_t any_over = __ballot(over != 0);
         if (threadIdx.x == kWave - 1) {
+            const uint32_t spilled = get(&ws.state[tile].over_count[slot]);
             sh->seg_prefix[g.n_seg] = incl;      // (n_seg <= 4 * 64: the last lane's inclusive sum is the total)
             sh->seg_total = total_raw;
-            sh->seg_overflow = any_over ? 1u : 0u;
+            sh->over_n = min(spilled, g.over_cap);
+            sh->seg_overflow = spilled > g.over_cap ? 1u : 0u;
         }
     }
 }
+
 // Every candidate of the slot once: a team of blockDim / n_seg consecutive threads per segment.  The first kPre records of a
 // thread are requested at the TOP of the kernel, before the segment fills are known (entries beyond a fill are in-bounds
 // garbage that is never used), so the stage pays one memory round trip for counters, moments and candidates together; a
@@ -735,8 +752,8 @@ __device__ __forceinline__ void prefetch_candidates(CandPrefetch<kPre>& pf, cons
 template <int kPre, class Fn>
 __device__ __forceinline__ void for_each_candidate(const CandPrefetch<kPre>& pf, const SlotScratch* sh, const Geometry& g, const float* __restrict__ c0, Fn fn) {
     const uint32_t team = blockDim.x / (uint32_t)g.n_seg, k = threadIdx.x / team, r = threadIdx.x - k * team;
-    if (k >= (uint32_t)g.n_seg) return;
-    const uint32_t first = sh->seg_prefix[k], cnt = sh->seg_prefix[k + 1] - first;
+    const bool mine = k < (uint32_t)g.n_seg;
+    const uint32_t first = mine ? sh->seg_prefix[k] : 0u, cnt = mine ? sh->seg_prefix[k + 1] - first : 0u;
     const float* src = c0 + (size_t)k * g.seg_cap;
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
@@ -744,6 +761,13 @@ __device__ __forceinline__ void for_each_candidate(const CandPrefetch<kPre>& pf,
         if (o < cnt) fn(first + o, pf.od[u]);
     }
     constexpr int kFlight = 4;
+    // the overflow area (rare): every thread, plain strided sweep
+    for (uint32_t o = threadIdx.x; o < sh->over_n; o += blockDim.x) {
+        const float* p = c0 + (size_t)g.n_seg * g.seg_cap + o;
+        const float od[3] = {get(&p[0]), get(&p[g.cap2]), get(&p[2 * (size_t)g.cap2])};
+        fn(sh->seg_prefix[g.n_seg] + o, od);
+    }
+    if (k >= (uint32_t)g.n_seg) return;
     for (uint32_t off = r + kPre * team; off < cnt; off += team * kFlight) {
         float od[kFlight][3];
 #pragma unroll
@@ -1039,7 +1063,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = sh.vecs[i];
         if (stamps) SX_STAMP(st, 9);
-        const uint32_t n = sh.seg_prefix[g.n_seg], n_raw = sh.seg_total;
+        const uint32_t n = sh.seg_prefix[g.n_seg] + sh.over_n, n_raw = sh.seg_total;
         use_all = sh.use_all != 0;
         const unsigned long long n_sel = sh.n_sel;
         const unsigned long long rank = nearest_rank_index(j ? 99.0 : 1.0, n_sel);      // alpha = 1 (torch_backend.py:421-422)
@@ -1139,7 +1163,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     for (int i = 0; i < 6; ++i) pinv[i] = sh.pinv[i];
     const unsigned long long n_all = (unsigned long long)g.pixels;
     const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
-    const uint32_t n = sh.seg_prefix[g.n_seg], n_raw = sh.seg_total;
+    const uint32_t n = sh.seg_prefix[g.n_seg] + sh.over_n, n_raw = sh.seg_total;
     if (stamps) SX_STAMP(st, 13);
     // every pixel that is not a candidate lies below the answer (that is what gets proved): the answer's rank among the candidates
     const unsigned long long outside = n_all - (unsigned long long)n;

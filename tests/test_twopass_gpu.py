@@ -136,3 +136,16 @@ def test_default_route_and_feedback(be, dev):
     assert fresh._classic_left > 0 and _same(first, second)
     classic = fresh.transform(xb, SM, TMC, _extra_flags=_native.MACENKO_CLASSIC)
     assert _same(first, classic)
+
+
+def test_tissue_concentrated_in_a_few_work_items(be, dev):
+    """A tile that is 90 % saturated background has all its concentration candidates in two of its sixteen work items: their
+    waves' segments overflow into the tile's overflow area (not into the slow path), and the bits are the four-pass form's."""
+    tiles = synth.he_batch(4, 512, 512, seed0=5)
+    tiles[..., : int(512 * 0.9), :] = 255
+    tiles[1, :, : int(512 * 0.5), :] = synth.he_batch(1, 512, 512, seed0=6)[0, :, : int(512 * 0.5), :]      # one tile with half tissue
+    for dt in (torch.float32, torch.uint8):
+        x = synth.as_dtype(tiles, dt).to(dev)
+        two, p2, classic, p1 = _both(be, x)
+        _check_equal(two, p2, classic, p1, dt)
+        assert int((p2["fell_back"] & 15).max()) == 0, (dt, p2["fell_back"])
