@@ -2180,11 +2180,12 @@ __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __
     const int per_tile = g.fine_chunk ? g.fine_blocks : g.blocks_per_tile;
     __shared__ LevelTables<T> tb;
     tb.fill();
+    const unsigned item = blockIdx.x;      // (measured: reversing the order, so that the work items pass A touched last come first, changes nothing)
     if constexpr (kInter && V > 1) {
         __shared__ uint4 stage[kStreamThreads * 3];      // 3 KB per wave: store_pixels_staged()
-        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix, tb, stage);
+        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, item / per_tile, item % per_tile, stain_matrix, tb, stage);
     } else {
-        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, stain_matrix, tb);
+        reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, item / per_tile, item % per_tile, stain_matrix, tb);
     }
 }
 
