@@ -71,6 +71,7 @@ struct alignas(16) PriorScratch {
     double red[kGroupThreads / kWave][kPartial];
     double mom[kMoments];
     uint32_t hist[4][kPriorBins];
+    uint32_t od16[kPriorSweeps][6][kGroupThreads];      // the sample's optical densities in fp16 (a thread's quad of a sweep: 12 halves), for the second look
     uint32_t n_kept, n_all, hazard, r_max;
     float frame[9];
     float bdir[4][2];
@@ -181,6 +182,15 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         for (int s = 0; s < kPriorSweeps; ++s) {
             float od[4][3];
             const bool have = prior_load<T, kVec, kInter>(img, g, s, od);
+            // (kept for the second look in fp16: brackets and thresholds of a SAMPLE need no more, and reading the pixels again
+            // -- from L2, with their logarithms -- was 3 us of this kernel)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int e = 2 * q;      // halves e, e + 1 of the quad's 12: element e = pixel e / 3, channel e % 3
+                typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+                const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(od[e / 3][e % 3], od[(e + 1) / 3][(e + 1) % 3]);
+                sh.od16[s][q][tid] = __builtin_bit_cast(uint32_t, h);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float* o = od[i];
@@ -263,7 +273,15 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
 #pragma unroll
         for (int s = 0; s < kPriorSweeps; ++s) {
             float od[4][3];
-            const bool have = prior_load<T, kVec, kInter>(img, g, s, od);
+            const bool have = s * (kGroupThreads / 4) + (tid >> 2) < g.prior_units;      // (as in prior_load)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                const half2v h = __builtin_bit_cast(half2v, sh.od16[s][q][tid]);      // (written by this thread: no barrier needed)
+                const int e = 2 * q;
+                od[e / 3][e % 3] = (float)h[0];
+                od[(e + 1) / 3][(e + 1) % 3] = (float)h[1];
+            }
             if (have) have_bits |= 1u << s;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -693,6 +711,7 @@ struct alignas(16) SlotScratch {
     uint32_t seg_prefix[kMaxSegments + 1], seg_total, seg_overflow, over_n;
     uint32_t own_key;
     int partner_ok;
+    uint32_t k_floor, k_ceil, n_under;      // concentration slots: keys below k_floor are counted, not ranked; keys above k_ceil share the last bin
 };
 
 // The slot's candidates lie in one segment per wave of pass A (+ the tile's overflow area): prefix sums of the segment fills
@@ -793,6 +812,7 @@ __device__ __forceinline__ void select_prepare(SlotScratch* sh) {
         sh->hi = 0u;
         sh->n_list = 0;
         sh->result = 0;
+        sh->n_under = 0;
     }
     for (int i = threadIdx.x; i < 512; i += blockDim.x) (&sh->t.hist_c[0][0])[i] = 0;
 }
@@ -813,12 +833,16 @@ __device__ __forceinline__ void publish_range(SlotScratch* sh, uint32_t mn, uint
 // Two levels of 256 value-linear bins: over the keys' range, then -- only when the picked bin holds more keys than the short
 // list -- over that bin's own key range.  Tiles from 8-bit data tie heavily (the same colour, the same key): a bin there
 // holds thousands of keys of a handful of values, which the second level separates or recognises as one value.
-__device__ uint32_t select_slot_keys(SlotScratch* sh, const uint32_t* __restrict__ spill, uint32_t n, uint32_t rank, bool level0_filled, unsigned long long* dbg = nullptr) {
+// k_floor / k_ceil: keys below k_floor take no part (the caller has counted them and taken them off `rank`); the bins span
+// [max(lo, k_floor), min(hi, k_ceil)], keys beyond share the last bin.
+__device__ uint32_t select_slot_keys(SlotScratch* sh, const uint32_t* __restrict__ spill, uint32_t n, uint32_t rank, bool level0_filled, unsigned long long* dbg = nullptr, uint32_t k_floor = 0u, uint32_t k_ceil = 0xFFFFFFFFu) {
     const uint32_t lane = lane_id();
     const int wave = threadIdx.x / kWave;
-    const uint32_t share = (n + blockDim.x - 1) / blockDim.x, i_begin = min(threadIdx.x * share, n), i_end = min(i_begin + share, n);
-    double origin = bin_origin_for(sh->lo), scale = bin_scale_for(sh->lo, sh->hi);      // (lo, hi: the keys' range, or the range the caller binned them over)
-    uint32_t k_first = 0u, k_last = 0xFFFFFFFFu, want = rank;      // the keys still in play: k_first <= key <= k_last
+    // (an ODD share: the lanes of a wave read words `share` apart, and an even stride folds them onto a fraction of the LDS banks)
+    const uint32_t share = ((n + blockDim.x - 1) / blockDim.x) | 1u, i_begin = min(threadIdx.x * share, n), i_end = min(i_begin + share, n);
+    const uint32_t lo = max(sh->lo, k_floor), hi = max(min(sh->hi, k_ceil), lo);
+    double origin = bin_origin_for(lo), scale = bin_scale_for(lo, hi);      // (lo, hi: the keys' range, or the range the caller binned them over)
+    uint32_t k_first = k_floor, k_last = 0xFFFFFFFFu, want = rank;      // the keys still in play: k_first <= key <= k_last
     uint32_t* hist = sh->t.hist_c[0];
     for (int level = 0; level < 2; ++level) {
         if (level > 0 || !level0_filled) {
@@ -874,7 +898,7 @@ __device__ uint32_t select_slot_keys(SlotScratch* sh, const uint32_t* __restrict
     }
     if (n_list <= (uint32_t)(2 * kSample)) return radix_select_stream((unsigned long long)n_list, (unsigned long long)want, [list](unsigned long long i, uint32_t& k) { k = list[i]; return true; }, &sh->t);
     // more keys than the list holds: radix rounds over all the keys
-    return radix_select_stream((unsigned long long)n, (unsigned long long)rank, [sh, spill](unsigned long long i, uint32_t& k) { k = slot_key(sh, spill, (uint32_t)i); return true; }, &sh->t);
+    return radix_select_stream((unsigned long long)n, (unsigned long long)rank, [sh, spill, k_floor](unsigned long long i, uint32_t& k) { k = slot_key(sh, spill, (uint32_t)i); return k >= k_floor; }, &sh->t);
 }
 
 // M = F^-1 X for the 3x3 frame F = [a0 a1 an] (columns) and the three-vector X: coordinates of X in the prior frame.
@@ -1138,6 +1162,13 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
         const bool good = mode == 0 && conc_slot_check(pr, pinv, j, theta, hi);
         sh.check[0] = theta;
         sh.ok = good ? 1 : 0;
+        // The answer has to reach theta (that is the proof): the four candidates in five that lie below it -- each end test
+        // lets through what the other one's threshold would have stopped -- are counted and stay out of the histograms.
+        const double bound = theta + 4e-6 * fabs(theta) + 1e-7;
+        uint32_t kf = float_key((float)bound);
+        if ((double)key_float(kf) > bound && kf > 0u) --kf;      // (the largest float <= bound; consecutive keys are consecutive floats)
+        sh.k_floor = good ? kf : 0u;
+        sh.k_ceil = good ? max(float_key(hi), kf) : 0xFFFFFFFFu;
     };
     if (threadIdx.x == kWave) {                  // (wave 1, meanwhile) the partner's key
         unsigned long long granule = 0;
@@ -1173,22 +1204,32 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + slot) * spill_words;
     uint32_t answer = 0;
     if (ok) {
-        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        const uint32_t k_floor = sh.k_floor, k_ceil = sh.k_ceil;
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u, under = 0u;
         for_each_candidate(pf, &sh, g, c1, [&](uint32_t i, const float (&od)[3]) {
             float ca, cb;
             concentration(od, pinv, ca, cb);
             const uint32_t k = float_key(j ? cb : ca);
             mn = min(mn, k);
             mx = max(mx, k);
+            under += k < k_floor ? 1u : 0u;
             if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
         });
         publish_range(&sh, mn, mx);
+        under = wave_total_u32(under);
+        if (lane_id() == 0 && under) atomicAdd(&sh.n_under, under);
         __syncthreads();
         if (stamps) SX_STAMP(st, 14);
-        answer = select_slot_keys(&sh, spill, n, (uint32_t)(k99 - outside), false);
-        const double a = (double)key_float(answer), theta = sh.check[0];
-        if (!(a >= theta + 4e-6 * fabs(theta) + 1e-7)) ok = false;
+        const unsigned long long rank_in = k99 - outside;
+        const uint32_t n_under = sh.n_under;
         why = 3u;
+        if (rank_in < n_under) {      // the answer lies below theta: the proof has failed
+            ok = false;
+        } else {
+            answer = select_slot_keys(&sh, spill, n, (uint32_t)(rank_in - n_under), false, nullptr, k_floor, k_ceil);
+            const double a = (double)key_float(answer), theta = sh.check[0];
+            if (!(a >= theta + 4e-6 * fabs(theta) + 1e-7)) ok = false;
+        }
     }
     if (!ok) {
         __syncthreads();
