@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
 // ------------------------------------------------------------------------------------------------
 template <int TPB> struct PassAScratch {
     StatsScratch<TPB> stats;
-    uint4 queue[TPB / kWave][kQueue2];
+    uint32_t queue[TPB / kWave][4][kQueue2];      // (od0, od1, od2, flags) as four planes: a record is four LDS stores of registers where they lie, no packing moves
     uint32_t below[2];
 };
 
@@ -463,12 +463,12 @@ template <int TPB> struct PassAScratch {
 // wave has produced so far.  What does not fit the segment (tissue concentrated in a few work items: a tile that is 90 %
 // background has all its candidates in two of them) goes to the tile's OVERFLOW area behind the segments, reserved with one
 // atomic per flush and slot -- the rare path.
-__device__ __forceinline__ void write_records(const uint4* __restrict__ queue, uint32_t n, uint32_t (&have)[kSlots], float* __restrict__ cand_tile, const Geometry& g, uint32_t seg_base, uint32_t* __restrict__ over_count) {
+__device__ __forceinline__ void write_records(const uint32_t (*__restrict__ queue)[kQueue2], uint32_t n, uint32_t (&have)[kSlots], float* __restrict__ cand_tile, const Geometry& g, uint32_t seg_base, uint32_t* __restrict__ over_count) {
     const uint32_t cap2 = g.cap2, seg_cap = g.seg_cap, over_base = (uint32_t)g.n_seg * g.seg_cap;
     for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
         const uint32_t i = i0 + lane_id();
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
-        if (i < n) rec = queue[i];
+        if (i < n) rec = make_uint4(queue[0][i], queue[1][i], queue[2][i], queue[3][i]);
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
             const bool has = ((rec.w >> s) & 1u) != 0;
@@ -533,7 +533,7 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
 #pragma unroll
     for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
 
-    uint4* queue = sh->queue[wave];
+    uint32_t (*queue)[kQueue2] = sh->queue[wave];
     uint32_t n_q = 0, have[kSlots] = {0u, 0u, 0u, 0u}, below_a = 0, below_b = 0;
     float* cand_tile = ws.cand_od + (size_t)tile * kSlots * 3 * g.cap2;
     const uint32_t seg = (uint32_t)chunk_id * (TPB / kWave) + (uint32_t)wave, seg_base = seg * g.seg_cap;
@@ -570,12 +570,15 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
             for (int i0 = 0; i0 < V; i0 += G) {
                 float od[G][3];
                 bool kept[G];
+                uint64_t valid[G];
                 float16v forms[G];
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) od[gi][c] = od_of<T>(u[c][i0 + gi], tb);
-                    kept[gi] = live && od_selected(od[gi], false);
+                    const bool sel = od_selected(od[gi], false);
+                    kept[gi] = live && sel;
+                    valid[gi] = __builtin_amdgcn_ballot_w64(sel) & live_mask;      // (the ballot of a bare comparison is the comparison's own mask; of `live && sel` it is a 0 / 1 register compared with 0 again)
                     if (kept[gi]) {      // (stats_item multiplies by a 0 / 1 `keep` instead: the same bits, four instructions more)
                         const float* o = od[gi];
                         m[0] += 1.0f;
@@ -615,13 +618,12 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
                         const float* o = od[gi];
                         const float16v& f = forms[gi];
                         const float mrg = fmaf(kw, fabsf(f[kRowW]), fmaf(kx, fabsf(o[0]) + fabsf(o[1]) + fabsf(o[2]), 1e-6f));
-                        const uint64_t valid = __builtin_amdgcn_ballot_w64(kept[gi]);
                         // angle slots: "below" is cross(d, th) < -m, "above" cross(d, th) > m; an open side has the zero row: never true
                         const uint64_t lt_a = __builtin_amdgcn_ballot_w64(f[kRowBelowA] < -mrg), gt_a = __builtin_amdgcn_ballot_w64(f[kRowAboveA] > mrg);
                         const uint64_t lt_b = __builtin_amdgcn_ballot_w64(f[kRowBelowB] < -mrg), gt_b = __builtin_amdgcn_ballot_w64(f[kRowAboveB] > mrg);
-                        below_a += (uint32_t)__popcll(valid & lt_a);
-                        below_b += (uint32_t)__popcll(valid & lt_b);
-                        const uint64_t c_a = valid & ~lt_a & ~gt_a, c_b = valid & ~lt_b & ~gt_b;
+                        below_a += (uint32_t)__popcll(valid[gi] & lt_a);
+                        below_b += (uint32_t)__popcll(valid[gi] & lt_b);
+                        const uint64_t c_a = valid[gi] & ~lt_a & ~gt_a, c_b = valid[gi] & ~lt_b & ~gt_b;
                         // concentration slots: every pixel takes part; a candidate reaches the threshold at either end direction
                         const uint64_t c_c = live_mask & (__builtin_amdgcn_ballot_w64(f[kRowConc] >= -mrg) | __builtin_amdgcn_ballot_w64(f[kRowConc + 1] >= -mrg));
                         const uint64_t c_d = live_mask & (__builtin_amdgcn_ballot_w64(f[kRowConc + 2] >= -mrg) | __builtin_amdgcn_ballot_w64(f[kRowConc + 3] >= -mrg));
@@ -631,7 +633,13 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
                             flags |= __builtin_amdgcn_inverse_ballot_w64(c_b) ? 2u : 0u;
                             flags |= __builtin_amdgcn_inverse_ballot_w64(c_c) ? 4u : 0u;
                             flags |= __builtin_amdgcn_inverse_ballot_w64(c_d) ? 8u : 0u;
-                            if (__builtin_amdgcn_inverse_ballot_w64(any)) queue[n_q + rank_in_mask(any)] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), flags);
+                            if (__builtin_amdgcn_inverse_ballot_w64(any)) {
+                                const uint32_t at = n_q + rank_in_mask(any);
+                                queue[0][at] = __float_as_uint(o[0]);
+                                queue[1][at] = __float_as_uint(o[1]);
+                                queue[2][at] = __float_as_uint(o[2]);
+                                queue[3][at] = flags;
+                            }
                             n_q += (uint32_t)__popcll(any);
                         }
                         if (__builtin_expect(n_q > (uint32_t)(kQueue2 - kWave), 0)) flush();      // the next pixel adds at most 64 records
