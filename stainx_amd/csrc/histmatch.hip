@@ -184,11 +184,14 @@ __device__ inline float torch_sum_256(At at) {
 __global__ void normalise_kernel(const uint32_t* __restrict__ counts, float* __restrict__ hist_out) {
     const int c = blockIdx.x;
     __shared__ float total_s;
+    __shared__ float raw[kBins];
+    raw[threadIdx.x] = (float)counts[c * kBins + threadIdx.x];
+    __syncthreads();
     if (threadIdx.x == 0) {
-        total_s = torch_sum_256([&](int b) { return (float)counts[c * kBins + b]; }) + 1e-8f;
+        total_s = torch_sum_256([&](int b) { return raw[b]; }) + 1e-8f;
     }
     __syncthreads();
-    hist_out[c * kBins + threadIdx.x] = (float)counts[c * kBins + threadIdx.x] / total_s;
+    hist_out[c * kBins + threadIdx.x] = raw[threadIdx.x] / total_s;
 }
 
 template <typename O> __device__ __forceinline__ uint64_t pack_elem(O v) {
@@ -209,31 +212,38 @@ __global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, co
     __shared__ float src_cdf[kBins], ref_cdf[kBins];
     __shared__ float src_term[kBins], ref_term[kBins];
     __shared__ float ref_denom_s;
+    __shared__ float ref_raw[kBins];
     // the divisions run one per thread; only the two running sums are sequential (that order is torch.cumsum's)
+    ref_raw[t] = ref_hist[c * kBins + t];      // (one load per thread: the summing thread reading global memory itself paid eight round trips)
+    __syncthreads();
     if (t == 64) {
         // reference: h / (sum(h) + 1e-8) (:222-223)
-        ref_denom_s = torch_sum_256([&](int b) { return ref_hist[c * kBins + b]; }) + 1e-8f;
+        ref_denom_s = torch_sum_256([&](int b) { return ref_raw[b]; }) + 1e-8f;
     }
     // source: counts / float(num_pixels + 1e-8) (:235)
     // (the local histogram is read as it was counted; counts pooled over ranks arrive widened to 64 bits)
     const unsigned long long count = counts32 ? (unsigned long long)counts32[c * kBins + t] : counts[c * kBins + t];
     src_term[t] = (float)count / (float)(num_pixels + 1e-8);
     __syncthreads();
-    ref_term[t] = ref_hist[c * kBins + t] / ref_denom_s;
+    ref_term[t] = ref_raw[t] / ref_denom_s;
     __syncthreads();
-    if (t == 0) {          // running sum in double rounded per entry (:236)
+    // running sum in double rounded per entry (:236): the order is torch.cumsum's, so one thread per table walks it -- sixteen
+    // terms are fetched from LDS at a time (one LDS latency per term made this kernel 11 us; the additions alone are ~1 us)
+    auto running_sum = [](const float* term, float* cdf) {
         double run = 0.0;
-        for (int b = 0; b < kBins; ++b) {
-            run += (double)src_term[b];
-            src_cdf[b] = (float)run;
+        for (int b0 = 0; b0 < kBins; b0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = term[b0 + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                run += (double)v[u];
+                cdf[b0 + u] = (float)run;
+            }
         }
-    } else if (t == 64) {
-        double run = 0.0;
-        for (int b = 0; b < kBins; ++b) {
-            run += (double)ref_term[b];
-            ref_cdf[b] = (float)run;
-        }
-    }
+    };
+    if (t == 0) running_sum(src_term, src_cdf);
+    else if (t == 64) running_sum(ref_term, ref_cdf);
     __syncthreads();
     const float s = src_cdf[t];
     // searchsorted(right=False): first index with ref_cdf[idx] >= s; clamp to [1,255] (:260-261)
