@@ -149,3 +149,26 @@ def test_tissue_concentrated_in_a_few_work_items(be, dev):
         two, p2, classic, p1 = _both(be, x)
         _check_equal(two, p2, classic, p1, dt)
         assert int((p2["fell_back"] & 15).max()) == 0, (dt, p2["fell_back"])
+
+
+def test_two_pass_replays_from_a_graph_on_new_data(be, dev):
+    """The four launches captured with the two-pass form forced (the router itself falls back to the four-pass form inside a
+    capture: it cannot read its telemetry there): a replay on other pixels in the same buffer gives the eager call's bits."""
+    a = synth.as_dtype(synth.he_batch(8, 256, 256, seed0=21), torch.float32).to(dev)
+    b = synth.as_dtype(synth.he_batch(8, 256, 256, seed0=22), torch.float32).to(dev)
+    sm, tmc = SM.to(dev), TMC.to(dev)
+    x = a.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            be.transform(x, sm, tmc, _extra_flags=_native.MACENKO_TWO_PASS)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = be.transform(x, sm, tmc, _extra_flags=_native.MACENKO_TWO_PASS)
+    x.copy_(b)
+    g.replay()
+    torch.cuda.synchronize()
+    replayed = out.clone()
+    eager = be.transform(b, sm, tmc, _extra_flags=_native.MACENKO_CLASSIC)
+    assert _same(replayed, eager)
