@@ -67,6 +67,8 @@ struct alignas(128) PriorRecord {
 };
 
 constexpr int kPriorBins = 2048;       // fixed-range histograms of the prior stage
+constexpr float kOpenWiden = 1.0f;      // an open bracket side's stand-in direction: this many bracket widths beyond the sample extreme
+constexpr float kOpenNear = 16.0f;      // ... used when the closed side has at least this many independent sample pixels on its near side
 struct alignas(16) PriorScratch {
     double red[kGroupThreads / kWave][kPartial];
     double mom[kMoments];
@@ -75,6 +77,7 @@ struct alignas(16) PriorScratch {
     uint32_t n_kept, n_all, hazard, r_max;
     float frame[9];
     float bdir[4][2];
+    float bkey[4], blevel[4];          // the four boundaries as diamond keys (before an open side is given its stand-in) and their quantile levels
     float cthr[4];
     uint32_t cmax[4];
     uint32_t open;
@@ -337,16 +340,37 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         const uint32_t rank = (uint32_t)min(max((int)(upper ? ceilf(pos) : floorf(pos)), 0), max(mv - 1, 0));
         const uint32_t b = prior_pick_bin(sh.hist[0], rank);
         if (lane == 0) {
-            // the bin's outer edge; an open side still needs a direction for the concentration tests: the range's end
-            float d = upper ? (float)(b + 1) * (2.0f / kPriorBins) : (float)b * (2.0f / kPriorBins);
-            if (open) d = upper ? 1.98f : 0.02f;
-            d = fminf(fmaxf(d, 0.02f), 1.98f);
-            float c, s;
-            direction_from_key(float_key(d), c, s);
-            sh.bdir[wave][0] = c;
-            sh.bdir[wave][1] = s;
+            // the bin's outer edge (an open side: the outer edge of the sample's extreme)
+            sh.bkey[wave] = upper ? (float)(b + 1) * (2.0f / kPriorBins) : (float)b * (2.0f / kPriorBins);
+            sh.blevel[wave] = fminf(fmaxf(level, 0.0f), 1.0f) * n_eff;      // (expected number of independent sample pixels on the low side of the boundary)
             if (open) atomicOr(&sh.open, 1u << wave);
         }
+    }
+    __syncthreads();
+    if (tid < 4) {
+        // An open side excludes no pixel from its angle slot, but the concentration tests still need a DIRECTION for that end of
+        // the cone the other stain vector lies in.  The range's end (what this used to be) is ~40 degrees from the data, and a
+        // test along it passes a different 2.5 % of the pixels than the test at the other end: twice the candidates (5.7 % per
+        // slot on config 2 against 4.5 % now; nothing widened: 4.0 %).  The stand-in is the sample's extreme moved outwards by the
+        // bracket's own width.  The wanted quantile lies beyond it only if NO independent sample pixel fell into a stretch that
+        // holds the quantile's own 1 % of the tile plus about what lies between the extreme and the closed boundary: e^-(0.01 n + m)
+        // for n independent pixels, m of them expected on the closed boundary's near side -- 2e-16 at n = 1024, m = 26; used from
+        // m = 16 on (n >= 450: 1e-9), the range's end otherwise.  If it happens the stage's cone check fails and the slot takes
+        // the slow exact path: a wrong guess costs time, never a bit.
+        const bool upper = (tid & 1) != 0, open = ((sh.open >> tid) & 1u) != 0, partner_open = ((sh.open >> (tid ^ 1)) & 1u) != 0;
+        float d = sh.bkey[tid];
+        if (open) {
+            const float other = sh.bkey[tid ^ 1];
+            const float n_eff = fmaxf((float)mv * (kSpecEff / 4.0f), 4.0f);
+            const float m_near = upper ? n_eff - sh.blevel[tid ^ 1] : sh.blevel[tid ^ 1];      // sample pixels between the partner boundary and this end
+            const bool tight = !partner_open && m_near >= kOpenNear;
+            d = !tight ? (upper ? 1.98f : 0.02f) : (upper ? d + kOpenWiden * fmaxf(d - other, 0.0f) + 2.0f / kPriorBins : d - kOpenWiden * fmaxf(other - d, 0.0f) - 2.0f / kPriorBins);
+        }
+        d = fminf(fmaxf(d, 0.02f), 1.98f);
+        float c, s;
+        direction_from_key(float_key(d), c, s);
+        sh.bdir[tid][0] = c;
+        sh.bdir[tid][1] = s;
     }
     __syncthreads();
     SX_STAMP(st, 5);
