@@ -42,7 +42,13 @@ constexpr int kPriorSweeps = 4;                       // 4-pixel quads a thread 
 constexpr int kPriorUnitsMax = kGroupThreads / 4 * kPriorSweeps;      // sectors of 16 pixels per tile: 1024
 constexpr int kQueue2 = 512;                          // 16-byte records a wave queues in LDS before it must flush
 constexpr float kSpecSigmas = 5.0f;                   // half-width of a bracket in standard deviations of the sample quantile
-constexpr float kSpecEff = 1.0f;                      // effective (independent) samples per 16-pixel sector
+// Independent samples per 16-pixel sector (four of its pixels enter the histograms: neighbours).  Sectors far apart -- at least
+// 8 sector lengths between sampled ones: tiles from ~360x360 -- are taken for TWO (sweeps over 3840 tiles of 512x512 / 256x256 and
+// the random stress lose no slot to it even at three, tools/sweep_cones.py; small tiles, where the sampled sectors are each other's
+// neighbours, lose a few at two and keep ONE).  A wrong guess costs time only: the slot's proof fails, the slow exact path runs,
+// and the host routes the next calls to the four-pass form.
+constexpr float kSpecEffFar = 2.0f, kSpecEffNear = 1.0f;
+__device__ __forceinline__ float spec_eff(const Geometry& g) { return g.prior_step_q16 >= (8u << 16) ? kSpecEffFar : kSpecEffNear; }
 constexpr float kSpecKw = 0.05f, kSpecKx = 1.3e-3f;   // margin m = kw |w| + kx |od|_1 + 1e-6 (kx: the fp16 rounding of the pixel, 2^-10, with room)
 constexpr uint32_t kSpecSlow = 1u, kSpecHazard = 2u;  // GroupState::spec bits
 constexpr int kMaxSegments = 256;                      // waves of pass A per tile (two_pass_size() keeps tiles within 64 work items)
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
     const int mv = (int)sh.n_kept, ms = (int)sh.n_all;
     if (wave < 4) {      // query `wave`: lower / upper boundary of slot 0, lower / upper boundary of slot 1
         const float f = wave < 2 ? 0.01f : 0.99f;
-        const float n_eff = fmaxf((float)mv * (kSpecEff / 4.0f), 4.0f);      // four histogram pixels per sector
+        const float n_eff = fmaxf((float)mv * (spec_eff(g) / 4.0f), 4.0f);      // four histogram pixels per sector
         const float sd = sqrtf(f * (1.0f - f) / n_eff);
         const bool upper = (wave & 1) != 0;
         const float level = upper ? f + kSpecSigmas * sd : f - kSpecSigmas * sd;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         float d = sh.bkey[tid];
         if (open) {
             const float other = sh.bkey[tid ^ 1];
-            const float n_eff = fmaxf((float)mv * (kSpecEff / 4.0f), 4.0f);
+            const float n_eff = fmaxf((float)mv * (spec_eff(g) / 4.0f), 4.0f);
             const float m_near = upper ? n_eff - sh.blevel[tid ^ 1] : sh.blevel[tid ^ 1];      // sample pixels between the partner boundary and this end
             const bool tight = !partner_open && m_near >= kOpenNear;
             d = !tight ? (upper ? 1.98f : 0.02f) : (upper ? d + kOpenWiden * fmaxf(d - other, 0.0f) + 2.0f / kPriorBins : d - kOpenWiden * fmaxf(other - d, 0.0f) - 2.0f / kPriorBins);
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
     __syncthreads();
     SX_STAMP(st, 6);
     if (wave < 4) {
-        const float n_eff = fmaxf((float)ms * (kSpecEff / 4.0f), 4.0f);
+        const float n_eff = fmaxf((float)ms * (spec_eff(g) / 4.0f), 4.0f);
         const float level = 0.99f - kSpecSigmas * sqrtf(0.99f * 0.01f / n_eff);
         const uint32_t rank = (uint32_t)max((int)floorf(fmaxf(level, 0.0f) * (float)max(ms - 1, 0)), 0);
         const uint32_t b = prior_pick_bin(sh.hist[wave], rank);
