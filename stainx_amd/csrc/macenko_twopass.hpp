@@ -73,8 +73,9 @@ struct alignas(128) PriorRecord {
 };
 
 constexpr int kPriorBins = 2048;       // fixed-range histograms of the prior stage
-constexpr float kOpenWiden = 1.0f;      // an open bracket side's stand-in direction: this many bracket widths beyond the sample extreme
-constexpr float kOpenNear = 16.0f;      // ... used when the closed side has at least this many independent sample pixels on its near side
+constexpr float kOpenExponent = 30.0f;  // an open bracket side's stand-in direction lies w bracket widths beyond the sample extreme, w in [1/4, 1] such that
+                                        // 0.01 n + w m >= this (the wanted quantile lies beyond it with probability ~e^-that: 1e-13)
+constexpr float kOpenNear = 16.0f;      // ... used when the closed side has at least this many independent sample pixels on its near side (m)
 struct alignas(16) PriorScratch {
     double red[kGroupThreads / kWave][kPartial];
     double mom[kMoments];
@@ -357,12 +358,13 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         // An open side excludes no pixel from its angle slot, but the concentration tests still need a DIRECTION for that end of
         // the cone the other stain vector lies in.  The range's end (what this used to be) is ~40 degrees from the data, and a
         // test along it passes a different 2.5 % of the pixels than the test at the other end: twice the candidates (5.7 % per
-        // slot on config 2 against 4.5 % now; nothing widened: 4.0 %).  The stand-in is the sample's extreme moved outwards by the
-        // bracket's own width.  The wanted quantile lies beyond it only if NO independent sample pixel fell into a stretch that
-        // holds the quantile's own 1 % of the tile plus about what lies between the extreme and the closed boundary: e^-(0.01 n + m)
-        // for n independent pixels, m of them expected on the closed boundary's near side -- 2e-16 at n = 1024, m = 26; used from
-        // m = 16 on (n >= 450: 1e-9), the range's end otherwise.  If it happens the stage's cone check fails and the slot takes
-        // the slow exact path: a wrong guess costs time, never a bit.
+        // slot on config 2 against 4.5 % with one bracket width added, 4.0 % with a quarter).  The stand-in is the sample's extreme
+        // moved outwards by w times the bracket's own width.  The wanted quantile lies beyond it only if NO independent sample
+        // pixel fell into a stretch that holds the quantile's own 1 % of the tile plus about w times what lies between the extreme
+        // and the closed boundary: e^-(0.01 n + w m) for n independent pixels, m of them expected on the closed boundary's near
+        // side; w is chosen for an exponent of 30 (kOpenExponent), between 1/4 and 1; with fewer than 16 pixels on the near side
+        // the range's end stays.  If it happens the stage's cone check fails and the slot takes the slow exact path: a wrong guess
+        // costs time, never a bit.
         const bool upper = (tid & 1) != 0, open = ((sh.open >> tid) & 1u) != 0, partner_open = ((sh.open >> (tid ^ 1)) & 1u) != 0;
         float d = sh.bkey[tid];
         if (open) {
@@ -370,7 +372,8 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
             const float n_eff = fmaxf((float)mv * (spec_eff(g) / 4.0f), 4.0f);
             const float m_near = upper ? n_eff - sh.blevel[tid ^ 1] : sh.blevel[tid ^ 1];      // sample pixels between the partner boundary and this end
             const bool tight = !partner_open && m_near >= kOpenNear;
-            d = !tight ? (upper ? 1.98f : 0.02f) : (upper ? d + kOpenWiden * fmaxf(d - other, 0.0f) + 2.0f / kPriorBins : d - kOpenWiden * fmaxf(other - d, 0.0f) - 2.0f / kPriorBins);
+            const float w = fminf(fmaxf((kOpenExponent - 0.01f * n_eff) / fmaxf(m_near, 1.0f), 0.25f), 1.0f);
+            d = !tight ? (upper ? 1.98f : 0.02f) : (upper ? d + w * fmaxf(d - other, 0.0f) + 2.0f / kPriorBins : d - w * fmaxf(other - d, 0.0f) - 2.0f / kPriorBins);
         }
         d = fminf(fmaxf(d, 0.02f), 1.98f);
         float c, s;
