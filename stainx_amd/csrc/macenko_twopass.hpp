@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     // ------------------------------------------------ concentration j
     if (stamps) SX_STAMP(st, 12);
     const float* c1 = ws.cand_od + ((size_t)tile * kSlots + slot) * 3 * g.cap2;
-    CandPrefetch<16> pf;
+    CandPrefetch<12> pf;
     prefetch_candidates(pf, g, c1);      // in flight while the partner finishes
     __syncthreads();                     // everyone is done with the first selection's scratch
     select_prepare(&sh);
