@@ -9,12 +9,14 @@
 // Every number that reaches the output is computed by the same device functions, in the same order, as on the classic
 // path: the two paths agree bit for bit (tests/test_twopass_gpu.py).
 //
-//   K0 prior_kernel   one workgroup per tile: presample -> approximate plane frame F = [a0 a1 an], the two angle
-//                     brackets as four boundary DIRECTIONS in the (a0,a1) plane, and per concentration slot two end
-//                     directions with a lower threshold each                                    (~6 % of the input)
+//   K0 prior_kernel   one workgroup per tile: presample (kept in LDS as fp16 for its second look) -> approximate plane frame
+//                     F = [a0 a1 an], the two angle brackets as four boundary DIRECTIONS in the (a0,a1) plane (an open
+//                     side: a stand-in just beyond the sample's extreme), and per concentration slot two end directions
+//                     with a lower threshold each                                               (~6 % of the input)
 //   K1 pass_a_kernel  the moments exactly as stats_kernel accumulates them + per pixel eight half-plane tests in the
-//                     prior frame; pixels that pass none are only counted, the others (~9 %) are queued in LDS and
-//                     written out per slot as optical-density triples                            (one read of the input)
+//                     prior frame (their linear forms on the matrix core); pixels that pass none are only counted, the
+//                     others (~7 %; 12 % counted per slot) are queued in LDS and written out per slot as optical-density
+//                     triples                                                                  (one read of the input)
 //   K2 estimate_stage two workgroups per tile: exact plane from the moments; workgroup j: exact keys of the candidates of
 //                     angle percentile j, exact order statistic, proof; hand-off of the two keys between the partners;
 //                     stain vectors, pseudo-inverse; the same for concentration j; scale
