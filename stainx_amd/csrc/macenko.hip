@@ -360,6 +360,62 @@ __device__ __forceinline__ void load_pixels(const T* __restrict__ img, int64_t p
     }
 }
 
+// The V pixels a thread holds, as the three packs arrived (16 bytes each on the vector paths): a pixel's channel is taken out
+// of them when its turn comes.  Held as floats -- 3 V registers for the current sweep and 3 V for the one in flight -- uint8
+// tiles (V = 16) made pass A a 204-register kernel (two waves per SIMD, half its workgroups waiting for a second round), and in
+// every loop that requests the next sweep's pixels ahead the conversion of 16- and 8-bit elements was done at once, i.e. the
+// loop WAITED for the load it had just issued (bracket passes of bf16 / f16 / uint8 tiles).
+template <typename T, int V, bool kInter>
+struct PixelPacks {
+    static constexpr int kWords = (int)(sizeof(T) * V + 3) / 4;      // 4 on the vector paths (16-byte packs)
+    uint32_t w[3][kWords];      // (32-bit words, not elements: a struct of sixteen bytes is taken apart into sixteen registers the moment it is loaded)
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) w[k][i] = 0u;
+    }
+    __device__ __forceinline__ void load(const T* __restrict__ img, int64_t pixels, int64_t p) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T* src = kInter ? img + 3 * p + k * V : img + k * pixels + p;
+            if constexpr (sizeof(T) * V == 16) {
+                const uint4 q = *reinterpret_cast<const uint4*>(src);
+                w[k][0] = q.x; w[k][1] = q.y; w[k][2] = q.z; w[k][3] = q.w;
+            } else if constexpr (sizeof(T) * V == 8) {
+                const uint2 q = *reinterpret_cast<const uint2*>(src);
+                w[k][0] = q.x; w[k][1] = q.y;
+            } else {
+                static_assert(V == 1 && sizeof(T) <= 4, "single elements of at most four bytes");
+                T v = src[0];
+                uint32_t bits = 0;
+                __builtin_memcpy(&bits, &v, sizeof(T));
+                w[k][0] = bits;
+            }
+        }
+    }
+    // channel c of pixel i, as load_pixels<T, V, kInter, sizeof(T) == 1> hands it over (uint8: the grey level's integer bits)
+    __device__ __forceinline__ float value(int c, int i) const {
+        const int idx = kInter ? 3 * i + c : c * V + i, k = idx / V, e = idx % V;
+        if constexpr (sizeof(T) == 1) {
+            return __uint_as_float((w[k][e / 4] >> (8 * (e % 4))) & 0xFFu);
+        } else if constexpr (sizeof(T) == 2) {
+            const uint16_t bits = (uint16_t)(w[k][e / 2] >> (16 * (e % 2)));
+            T v;
+            __builtin_memcpy(&v, &bits, 2);
+            return raw_value<T>(v);
+        } else if constexpr (sizeof(T) == 4) {
+            T v;
+            __builtin_memcpy(&v, &w[k][e], 4);
+            return raw_value<T>(v);
+        } else {
+            T v;
+            __builtin_memcpy(&v, &w[k][2 * e], 8);
+            return raw_value<T>(v);
+        }
+    }
+};
+
 template <typename O, int V, bool kInter>
 __device__ __forceinline__ void store_pixels(O* __restrict__ dst, int64_t pixels, int64_t p, const O (&res)[3][V]) {
     if constexpr (kInter) {
@@ -1155,18 +1211,18 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
         for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
         const int64_t run_end = min(run + (int64_t)TPB * V * kShortRun, p_end);
         for (int64_t p = run + (int64_t)threadIdx.x * V; p < run_end; p += (int64_t)TPB * V) {
-            float u[3][V];
-            load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p, u);
+            PixelPacks<T, V, kInter> u;
+            u.load(img, g.pixels, p);
             // sample j sits in the cell [j*stride, (j+1)*stride) of its group at a hashed offset (a fixed offset would alias
             // with the image width: stride 1024 on a 2048-wide tile samples two columns only); tested once per pack
             const uint32_t gpos = group_offset + (uint32_t)p, j = gpos >> shift, off = sample_offset_in(j, shift, group_count);
             if (by_pack && (((gpos & mask) ^ off) >> kLog2V) == 0u && j < sample_count) {
-                float raw[3] = {u[0][0], u[1][0], u[2][0]};
+                float raw[3] = {u.value(0, 0), u.value(1, 0), u.value(2, 0)};
 #pragma unroll
                 for (int i = 1; i < V; ++i)
                     if ((int)(off & (uint32_t)(V - 1)) == i) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) raw[c] = u[c][i];
+                        for (int c = 0; c < 3; ++c) raw[c] = u.value(c, i);
                     }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od_of<T>(raw[c], tb));
@@ -1175,7 +1231,7 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
             for (int i = 0; i < V; ++i) {
                 float od[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u[c][i], tb);
+                for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u.value(c, i), tb);
                 if (!by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
                     const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
                     if ((pos & mask) == sample_offset_in(jj, shift, group_count) && jj < sample_count) {
@@ -1285,14 +1341,9 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
     // carries `live == false`); the first pack is requested before anything else, the stage record right behind it.
     int64_t base = p_begin + (int64_t)wave * kWave * V;
     const int64_t mine = (int64_t)lane_id() * V;
-    float next[3][V];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int i = 0; i < V; ++i) next[c][i] = 0.0f;
-    if (base + mine < p_end) {
-        load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, base + mine, next);
-    }
+    PixelPacks<T, V, kInter> next;
+    next.clear();
+    if (base + mine < p_end) next.load(img, g.pixels, base + mine);
     StageRecord rec;
     load_record(&st.rec[kConc ? 1 : 0], rec);
     for (int i = threadIdx.x; i < 512; i += TPB) (&sh->hist[0][0])[i] = 0;
@@ -1313,20 +1364,14 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 
     for (; base < p_end; base += (int64_t)TPB * V) {
         const uint64_t live_mask = __builtin_amdgcn_ballot_w64(base + mine < p_end);
-        float u[3][V];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int i = 0; i < V; ++i) u[c][i] = next[c][i];
+        const PixelPacks<T, V, kInter> u = next;
         const int64_t p_next = base + (int64_t)TPB * V + mine;
-        if (p_next < p_end) {
-            load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p_next, next);
-        }
+        if (p_next < p_end) next.load(img, g.pixels, p_next);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float od[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u[c][i], tb);
+            for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u.value(c, i), tb);
             uint32_t key_a, key_b;
             if constexpr (kConc) {
                 float c0, c1;

@@ -578,12 +578,9 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
     };
 
     const int64_t mine = (int64_t)threadIdx.x * V;
-    float next[3][V];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int i = 0; i < V; ++i) next[c][i] = 0.0f;
-    if (p_begin + mine < p_end) load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p_begin + mine, next);
+    PixelPacks<T, V, kInter> next;
+    next.clear();
+    if (p_begin + mine < p_end) next.load(img, g.pixels, p_begin + mine);
     __syncthreads();      // the scratch words above
 
     int in_run = 0;
@@ -593,13 +590,9 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
         constexpr int G = 1;      // pixels whose MFMAs are in flight together (measured: two together 48.3 us against 46.5 -- 16 more accumulator registers, and the other waves of the SIMD cover one MFMA's latency anyway)
         for (int64_t base_p = p_begin; base_p < p_end; base_p += (int64_t)TPB * V) {
             const bool live = base_p + mine < p_end;
-            float u[3][V];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int i = 0; i < V; ++i) u[c][i] = next[c][i];
+            const PixelPacks<T, V, kInter> u = next;
             const int64_t p_next = base_p + (int64_t)TPB * V + mine;
-            if (p_next < p_end) load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p_next, next);
+            if (p_next < p_end) next.load(img, g.pixels, p_next);
             const uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
 #pragma unroll
             for (int i0 = 0; i0 < V; i0 += G) {
@@ -610,7 +603,7 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) od[gi][c] = od_of<T>(u[c][i0 + gi], tb);
+                    for (int c = 0; c < 3; ++c) od[gi][c] = od_of<T>(u.value(c, i0 + gi), tb);
                     const bool sel = od_selected(od[gi], false);
                     kept[gi] = live && sel;
                     valid[gi] = __builtin_amdgcn_ballot_w64(sel) & live_mask;      // (the ballot of a bare comparison is the comparison's own mask; of `live && sel` it is a 0 / 1 register compared with 0 again)
@@ -680,6 +673,9 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
                         if (__builtin_expect(n_q > (uint32_t)(kQueue2 - kWave), 0)) flush();      // the next pixel adds at most 64 records
                     }
                 }
+                // (narrow pixels: 8 or 16 of these bodies in a row, and the scheduler would start all their table reads and
+                // logarithms together -- 48 optical densities live at once, a 200-register kernel at half the occupancy)
+                if constexpr (V > 4) __builtin_amdgcn_sched_barrier(0);
             }
             if (++in_run == kShortRun) {
 #pragma unroll
