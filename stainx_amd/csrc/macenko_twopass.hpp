@@ -882,6 +882,8 @@ __device__ uint32_t select_slot_keys(SlotScratch* sh, const uint32_t* __restrict
     const uint32_t lo = max(sh->lo, k_floor), hi = max(min(sh->hi, k_ceil), lo);
     double origin = bin_origin_for(lo), scale = bin_scale_for(lo, hi);      // (lo, hi: the keys' range, or the range the caller binned them over)
     uint32_t k_first = k_floor, k_last = 0xFFFFFFFFu, want = rank;      // the keys still in play: k_first <= key <= k_last
+    uint32_t picked = 0;
+    bool by_bin = false;      // the picked bin's keys are told by bin_of(), not by a key range
     uint32_t* hist = sh->t.hist_c[0];
     for (int level = 0; level < 2; ++level) {
         if (level > 0 || !level0_filled) {
@@ -896,33 +898,44 @@ __device__ uint32_t select_slot_keys(SlotScratch* sh, const uint32_t* __restrict
             uint32_t b, rb;
             scan_pick32(hist, want, b, rb);
             if (lane == 0) {
-                uint32_t first, last;
-                bin_key_range(b, origin, scale, first, last);
+                const uint32_t in_bin = hist[b];
                 sh->bin = b;
                 sh->rank_in_bin = rb;
-                sh->range_first = max(first, k_first);
-                sh->range_last = min(last, k_last);
-                sh->bin_count = hist[b];
+                sh->bin_count = in_bin;
+                // The bin's key range is only needed where the search goes on INSIDE the bin; a short bin is listed by asking every
+                // key for its bin again (one subtraction and one multiplication per key instead of ~150 dependent instructions on
+                // this one lane -- fp64 edges walked to the exact boundary -- while the workgroup waits).
+                if (in_bin > (uint32_t)kShortList || level == 1) {
+                    uint32_t first, last;
+                    bin_key_range(b, origin, scale, first, last);
+                    sh->range_first = max(first, k_first);
+                    sh->range_last = min(last, k_last);
+                }
             }
         }
         __syncthreads();
+        want = sh->rank_in_bin;
+        picked = sh->bin;
+        const uint32_t in_bin = sh->bin_count;
+        if (in_bin <= (uint32_t)kShortList && level == 0) {      // uniform; the rule
+            by_bin = true;
+            break;
+        }
         k_first = sh->range_first;
         k_last = sh->range_last;
-        want = sh->rank_in_bin;
-        const uint32_t in_bin = sh->bin_count;
-        if (in_bin <= (uint32_t)kShortList || level == 1) break;      // uniform
+        if (level == 1) break;
         // (tighten to the keys actually present in the bin?  not needed: the bin's own range is already 1/256 of the first)
         if (k_first == k_last) return k_first;                      // one key value fills the bin
         hist = sh->t.hist_c[1];      // zeroed by select_prepare
         origin = bin_origin_for(k_first);
         scale = bin_scale_for(k_first, k_last);
     }
-    if (k_first == k_last) return k_first;
+    if (!by_bin && k_first == k_last) return k_first;
     // the keys of the picked bin (at most the short list's worth, ties aside), listed and ranked by counting
     uint32_t* list = &sh->t.keys[0][0];      // 2 * kSample entries
     for (uint32_t i = i_begin; i < i_end; ++i) {
         const uint32_t k = slot_key(sh, spill, i);
-        if (k >= k_first && k <= k_last) {
+        if (k >= k_first && k <= k_last && (!by_bin || bin_of(k, origin, scale) == picked)) {
             const uint32_t at = atomicAdd(&sh->n_list, 1u);
             if (at < (uint32_t)(2 * kSample)) list[at] = k;
         }
