@@ -82,6 +82,10 @@ int sx_macenko_transform(const void* images_dev, void* out_dev, int dtype, int64
  * SX_MACENKO_CLASSIC for such data: the four-pass form has no such cliff.  Zero for calls that took the four-pass form. */
 size_t sx_macenko_telemetry_offset(void);
 
+/* 1 if sx_macenko_transform takes its two-pass form for such a call (element type, batch, tile size, flags), 0 for the four-pass
+ * form: a host only needs to watch the telemetry word after calls of the first kind. */
+int sx_macenko_takes_two_pass(int dtype, int64_t n_tiles, int64_t height, int64_t width, unsigned flags);
+
 /* Replaces MacenkoTorch.compute_reference_stain_matrix_torch (torch_backend.py:463-519): one stain
  * estimate pooled over all n_tiles*H*W pixels, no "<3 kept pixels" fallback.
  *   he_out_dev 6 floats (3,2) row-major;  max_c_out_dev 2 floats */

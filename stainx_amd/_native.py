@@ -44,6 +44,7 @@ SIGNATURES = {
     "sx_macenko_fit": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sx_macenko_tile_params": (_int, [_vp, _i64, _vp, _vp]),
     "sx_macenko_telemetry_offset": (_sz, []),
+    "sx_macenko_takes_two_pass": (_int, [_int, _i64, _i64, _i64, _uint]),
     "sx_macenko_dfit_state_bytes": (_sz, []),
     "sx_macenko_dfit_moments": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sx_macenko_dfit_begin": (_int, [_vp, _vp, _vp]),

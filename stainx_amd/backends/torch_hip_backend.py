@@ -117,7 +117,10 @@ class MacenkoHIP(TorchHIPBackendBase):
             ws = self._scratch.get(nbytes, self.device)
             flags = ((_native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0) | (_native.MACENKO_CHANNELS_LAST if channels_last else 0)
                      | (_native.MACENKO_SAMPLED if self._precision == "sampled" else 0) | int(_extra_flags))
-            routed = not (flags & (_native.MACENKO_CLASSIC | _native.MACENKO_TWO_PASS | _native.MACENKO_SAMPLED))
+            # (only calls the library would run in its two-pass form take part in the feedback: for the others -- small batches,
+            # narrow pixels -- the event, the side-stream copy and the stream bookkeeping are 7 us of host time per call for nothing)
+            routed = (not (flags & (_native.MACENKO_CLASSIC | _native.MACENKO_TWO_PASS | _native.MACENKO_SAMPLED))
+                      and self._lib.sx_macenko_takes_two_pass(code, n, h, w, flags) == 1)
             if routed:
                 flags |= self._route()
             rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),

@@ -2764,6 +2764,19 @@ extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, in
     return macenko::workspace_bytes(n_tiles, height * width);
 }
 
+// Which form sx_macenko_transform takes for a call (1: two-pass).  Where the two-pass form pays (measured, tools/bench_twopass.py):
+// 4- and 8-byte pixels in batches of at least ~4 M pixels and tiles up to ~724 x 724.  Narrow pixels (uint8 / bf16 / f16) make the
+// four passes cheap -- the two forms are level there (120 vs 123 us, 128 vs 132 us) --, big tiles put tens of thousands of
+// candidates on one stage workgroup.  SX_MACENKO_TWO_PASS asks for it wherever it is able to run (tests, A/B runs).
+extern "C" int sx_macenko_takes_two_pass(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) {
+    static const bool env_classic = std::getenv("STAINX_MACENKO_CLASSIC") != nullptr;      // A/B switch for benchmarks
+    if (n <= 0 || h <= 0 || w <= 0 || (flags & SX_MACENKO_SAMPLED)) return 0;
+    const int64_t pixels = h * w;
+    const bool pays = (dtype == SX_F32 || dtype == SX_F64) && pixels >= 16384 && pixels <= (1ll << 19) && n * pixels >= (1ll << 22);
+    const bool wanted = (flags & SX_MACENKO_TWO_PASS) != 0 || (pays && !(flags & SX_MACENKO_CLASSIC) && !env_classic);
+    return (wanted && two_pass_size(pixels)) ? 1 : 0;
+}
+
 extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* sm, const float* tmc, unsigned flags, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
     int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
     if (rc != SX_OK) return rc;
@@ -2776,16 +2789,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     g.no_tie = (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0;
     g.out_code = (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0);
     g.spec_fail = (flags & SX_MACENKO_SPEC_FAIL) ? 1 : 0;
-    {
-        static const bool env_classic = std::getenv("STAINX_MACENKO_CLASSIC") != nullptr;      // A/B switch for benchmarks
-        // Where the two-pass form pays (measured, tools/bench_twopass.py): 4- and 8-byte pixels in batches of at least ~4 M pixels
-        // and tiles up to ~724 x 724.  Narrow pixels (uint8 / bf16 / f16) make the four passes cheap and the two-pass form's fixed
-        // stages dominate (152 vs 122 us, 161 vs 131 us); big tiles put tens of thousands of candidates on one stage workgroup.
-        // SX_MACENKO_TWO_PASS asks for it wherever it is able to run (tests, A/B runs).
-        const bool pays = (dtype == SX_F32 || dtype == SX_F64) && g.pixels >= 16384 && g.pixels <= (1ll << 19) && n * g.pixels >= (1ll << 22);
-        const bool wanted = (flags & SX_MACENKO_TWO_PASS) != 0 || (pays && !(flags & SX_MACENKO_CLASSIC) && !env_classic);
-        g.two_pass = (!g.fast && wanted && two_pass_size(g.pixels)) ? 1 : 0;
-    }
+    g.two_pass = sx_macenko_takes_two_pass(dtype, n, h, w, flags);
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
