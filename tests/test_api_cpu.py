@@ -31,6 +31,14 @@ def test_library_exports_every_declared_symbol():
     assert _native.require().sx_macenko_workspace_bytes(64, 512, 512) > 0
     assert _native.require().sx_macenko_workspace_bytes(0, 512, 512) == 0
     assert _native.require().sx_hm_workspace_bytes(1, 8, 8) >= 3 * 256 * 8
+    # which form of the Macenko transform a call takes (host logic only): wide pixels in big batches of mid-sized tiles
+    takes = _native.require().sx_macenko_takes_two_pass
+    f32, u8, bf16 = _native.DTYPE_CODES[torch.float32], _native.DTYPE_CODES[torch.uint8], _native.DTYPE_CODES[torch.bfloat16]
+    assert takes(f32, 64, 512, 512, 0) == 1 and takes(_native.DTYPE_CODES[torch.float64], 64, 512, 512, 0) == 1
+    assert takes(f32, 1, 512, 512, 0) == 0 and takes(f32, 4, 2048, 2048, 0) == 0 and takes(f32, 1024, 64, 64, 0) == 0
+    assert takes(u8, 64, 512, 512, 0) == 0 and takes(bf16, 256, 224, 224, 0) == 0
+    assert takes(f32, 64, 512, 512, _native.MACENKO_CLASSIC) == 0 and takes(f32, 64, 512, 512, _native.MACENKO_SAMPLED) == 0
+    assert takes(u8, 4, 128, 128, _native.MACENKO_TWO_PASS) == 1 and takes(f32, 1, 8, 8, _native.MACENKO_TWO_PASS) == 0
 
 
 def test_public_surface():
