@@ -430,7 +430,19 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         return [hists[c] for c in range(3)]
 
     def _stack_reference(self, reference_histogram, chans: int) -> torch.Tensor:
-        # list -> (C,256): pad with the first histogram / trim (torch_cuda_backend.py:51-74)
+        # list -> (C,256): pad with the first histogram / trim (torch_cuda_backend.py:51-74).  The normaliser hands over the same
+        # fitted tensors on every call: the stacked copy is kept while they are the same objects at the same version (the
+        # torch.stack was a 5 us kernel and a launch gap in front of every transform).
+        parts = tuple(reference_histogram) if isinstance(reference_histogram, (list, tuple)) else (reference_histogram,)
+        cached = getattr(self, "_ref_cache", None)
+        if (cached is not None and cached[0] == chans and len(cached[1]) == len(parts)
+                and all(isinstance(p, torch.Tensor) and p is q and p._version == v for p, q, v in zip(parts, cached[1], cached[2]))):
+            return cached[3]
+        ref = self._stack_reference_uncached(reference_histogram, chans)
+        self._ref_cache = (chans, parts, tuple(p._version for p in parts), ref)      # (holds the sources: their identities cannot be reused meanwhile)
+        return ref
+
+    def _stack_reference_uncached(self, reference_histogram, chans: int) -> torch.Tensor:
         if isinstance(reference_histogram, (list, tuple)):
             if len(reference_histogram) == 0:
                 raise ValueError("reference_histogram list cannot be empty")
