@@ -76,10 +76,12 @@ int sx_macenko_transform(const void* images_dev, void* out_dev, int dtype, int64
                          int64_t width, const float* stain_matrix_dev, const float* target_max_conc_dev,
                          unsigned flags, void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Byte offset, inside the workspace of the LAST sx_macenko_transform, of a uint32 that holds how many of the batch's per-tile
- * selections left the speculative path of the two-pass form (tiles without tissue, tiles without a stable stain plane ...: each
- * costs a whole-tile exact select, ~0.1-0.5 ms).  A host that sees it non-zero (read back asynchronously) should pass
- * SX_MACENKO_CLASSIC for such data: the four-pass form has no such cliff.  Zero for calls that took the four-pass form. */
+/* Byte offset, inside the workspace, of a uint32 RUNNING count of per-tile selections that left the speculative path of the
+ * two-pass form (tiles without tissue, tiles without a stable stain plane ...: each costs a whole-tile exact select, ~0.1-0.5 ms).
+ * The library only ever adds to it (its value in a fresh workspace is whatever the memory held): a host reads it back
+ * asynchronously, takes the difference to what it read before, and passes SX_MACENKO_CLASSIC for data that makes it grow -- the
+ * four-pass form has no such cliff.  (A count per call would be reset by the next call's first kernel before a host that lets
+ * its calls queue up could read it.) */
 size_t sx_macenko_telemetry_offset(void);
 
 /* 1 if sx_macenko_transform takes its two-pass form for such a call (element type, batch, tile size, flags), 0 for the four-pass

@@ -72,6 +72,9 @@ class MacenkoHIP(TorchHIPBackendBase):
         self._tele_stream: torch.cuda.Stream | None = None
         self._classic_left = 0
         self._classic_span = 32
+        self._tele_age = 0
+        self._tele_ptr = 0
+        self._tele_base = (0, 0)      # (workspace pointer, the count read there last)
 
     @staticmethod
     def _check_images(images: torch.Tensor, what: str) -> None:
@@ -122,6 +125,9 @@ class MacenkoHIP(TorchHIPBackendBase):
             routed = (not (flags & (_native.MACENKO_CLASSIC | _native.MACENKO_TWO_PASS | _native.MACENKO_SAMPLED))
                       and self._lib.sx_macenko_takes_two_pass(code, n, h, w, flags) == 1)
             if routed:
+                if self._tele_base[0] != ws.data_ptr() and not torch.cuda.is_current_stream_capturing():
+                    # a workspace seen for the first time (first call, or the scratch grew): where its running count stands
+                    self._tele_base = (ws.data_ptr(), int(ws[self._tele_offset:self._tele_offset + 4].view(torch.int32).item()) & 0xFFFFFFFF)
                 flags |= self._route()
             rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),
                                                 flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -135,8 +141,21 @@ class MacenkoHIP(TorchHIPBackendBase):
         """Flag for this call: the four-pass form while a recent call reported tiles the two-pass form could not speculate on."""
         if torch.cuda.is_current_stream_capturing():
             return _native.MACENKO_CLASSIC      # a captured call is replayed on data nobody has seen: the form without a cliff (and no event may be queried here)
+        if self._tele_event is not None:
+            self._tele_age += 1
+            if self._tele_age > 4 and not self._tele_event.query():
+                # The host runs ahead of the device (a loop that never synchronises queues its calls long before they run): an
+                # answer that is five calls old is waited for, so that a batch the two-pass form cannot speculate on costs a few
+                # slow calls, not every call until the host happens to synchronise.  Five calls are still queued behind the one
+                # waited for: the device does not run dry.
+                self._tele_event.synchronize()
         if self._tele_event is not None and self._tele_event.query():
-            slow = int(self._tele_host[0])
+            # a running count (the library only adds to it): what is new since the last look at this workspace; the first look at a
+            # workspace only sets the base (fresh memory holds anything)
+            now = int(self._tele_host[0]) & 0xFFFFFFFF
+            slow = ((now - self._tele_base[1]) & 0xFFFFFFFF) if self._tele_base[0] == self._tele_ptr else 0
+            if self._tele_base[0] == self._tele_ptr:
+                self._tele_base = (self._tele_ptr, now)
             self._tele_event = None
             if slow > 0:
                 self._classic_left = self._classic_span
@@ -165,6 +184,8 @@ class MacenkoHIP(TorchHIPBackendBase):
             ev.record(self._tele_stream)
         ws.record_stream(self._tele_stream)
         self._tele_event = ev
+        self._tele_ptr = ws.data_ptr()
+        self._tele_age = 0
 
     def compute_reference_stain_matrix(self, images: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         """Pooled stain estimate ``(HE (3,2), maxC (2,))`` (compute_reference_stain_matrix_torch, :463-519)."""

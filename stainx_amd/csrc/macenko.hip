@@ -79,7 +79,8 @@ struct alignas(256) GroupState {
     uint32_t spec;                // two-pass transform (macenko_twopass.hpp): kSpecSlow | kSpecHazard
     unsigned long long phi_pub[2];      // two-pass transform: {tag, angle key} granules the two stage workgroups of a tile hand each other
     uint32_t over_count[kSlots];  // two-pass transform: candidates of the tile that did not fit their wave's segment (overflow area fill)
-    uint32_t slow_slots;          // two-pass transform, tile 0 only: selections of the whole batch that left the speculative path (telemetry)
+    uint32_t slow_slots;          // two-pass transform, tile 0 only: a RUNNING count of selections that left the speculative path (telemetry: only ever added to,
+                                  // so that a host that reads it late -- the next call's kernels may already be running -- still sees what happened)
     unsigned long long stamp[16]; // diagnostic: wall_clock64() at stage boundaries of the per-tile stages
 };
 
@@ -1632,7 +1633,6 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
         put(&st.n_sel, n_sel);
         put(&st.fell_back, 0u);
         put(&st.spec, 0u);
-        if (group == 0) put(&st.slow_slots, 0u);      // (telemetry of the two-pass form: nothing to report from here)
 #pragma unroll
         for (int s = 0; s < kSlots; ++s) {
             put(&st.below[s], 0u);

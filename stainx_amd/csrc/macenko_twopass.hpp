@@ -175,7 +175,6 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         put(&st.over_count[tid], 0u);
     }
     if (tid < 2) put(&st.phi_pub[tid], 0ull);
-    if (tile == 0 && tid == 0) put(&st.slow_slots, 0u);      // (tile 0's word counts for the batch)
     if (tid == 0) {
         put(&st.fell_back, 0u);
         put(&st.spec, 0u);
