@@ -454,13 +454,20 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         # list -> (C,256): pad with the first histogram / trim (torch_cuda_backend.py:51-74).  The normaliser hands over the same
         # fitted tensors on every call: the stacked copy is kept while they are the same objects at the same version (the
         # torch.stack was a 5 us kernel and a launch gap in front of every transform).
+        # Not cached: tensors made under torch.inference_mode() (they track no version: an in-place change would go unseen -- and
+        # reading `_version` raises), and anything while a stream capture is on (the stacked copy would only be filled at replay).
         parts = tuple(reference_histogram) if isinstance(reference_histogram, (list, tuple)) else (reference_histogram,)
+        cacheable = (all(isinstance(p, torch.Tensor) and not p.is_inference() for p in parts)
+                     and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()))
+        if not cacheable:
+            return self._stack_reference_uncached(reference_histogram, chans)
+        stamp = tuple((p.data_ptr(), tuple(p.shape), p._version) for p in parts)
         cached = getattr(self, "_ref_cache", None)
         if (cached is not None and cached[0] == chans and len(cached[1]) == len(parts)
-                and all(isinstance(p, torch.Tensor) and p is q and p._version == v for p, q, v in zip(parts, cached[1], cached[2]))):
+                and all(p is q for p, q in zip(parts, cached[1])) and cached[2] == stamp):
             return cached[3]
         ref = self._stack_reference_uncached(reference_histogram, chans)
-        self._ref_cache = (chans, parts, tuple(p._version for p in parts), ref)      # (holds the sources: their identities cannot be reused meanwhile)
+        self._ref_cache = (chans, parts, stamp, ref)      # (holds the sources: their identities cannot be reused meanwhile)
         return ref
 
     def _stack_reference_uncached(self, reference_histogram, chans: int) -> torch.Tensor:

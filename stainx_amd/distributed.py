@@ -31,7 +31,14 @@ import torch.distributed as dist
 
 # STAINX_FORCE_COLLECTIVES=1 (or force=True): a process group of ONE rank still goes through dist.all_reduce / all_gather, so that
 # the RCCL path can be exercised -- and timed -- on a one-GPU box (tests/test_distributed_gpu.py, bench.py --workload fit_transform_pooled).
-FORCE_COLLECTIVES = bool(os.environ.get("STAINX_FORCE_COLLECTIVES"))
+# Read at every call (not frozen at import); only "1" / "true" / "yes" / "on" switch it on -- "0" does not.
+FORCE_COLLECTIVES: bool | None = None      # a test or a driver may set this module attribute to override the environment
+
+
+def force_collectives() -> bool:
+    if FORCE_COLLECTIVES is not None:
+        return bool(FORCE_COLLECTIVES)
+    return os.environ.get("STAINX_FORCE_COLLECTIVES", "").strip().lower() in ("1", "true", "yes", "on")
 
 
 # bench.py --workload fit_transform_pooled: device time spent inside the collectives (HIP events around every dist call)
@@ -73,7 +80,7 @@ def _timed(fn, *args, **kwargs):
 def _skip_collective(size: int, force: bool | None) -> bool:
     if not (dist.is_available() and dist.is_initialized()):
         return True
-    return size == 1 and not (FORCE_COLLECTIVES if force is None else force)
+    return size == 1 and not (force_collectives() if force is None else force)
 
 
 def world(group=None) -> tuple[int, int]:
@@ -158,8 +165,10 @@ def macenko_fit_pooled(local_images: torch.Tensor, *, group=None, steps: Any | N
         steps = MacenkoHIP(device if device is not None else local_images.device)
     if method not in ("brackets", "radix"):
         raise ValueError(f"method must be 'brackets' or 'radix', got {method!r}")
+    # (both methods: a rank without tiles must fail on EVERY rank here, not leave the others in the next collective)
+    tiles = tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
     if method == "brackets" and hasattr(steps, "pfit_stats"):
-        result = _macenko_fit_pooled_brackets(local_images, group, steps)
+        result = _macenko_fit_pooled_brackets(local_images, group, steps, tiles)
         if result is not None:
             return result
     moments = all_reduce_sum(steps.dfit_moments(local_images), group)
@@ -171,12 +180,15 @@ def macenko_fit_pooled(local_images: torch.Tensor, *, group=None, steps: Any | N
     return steps.dfit_result(state)
 
 
-def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps):
-    rank, size = world(group)
+def _exchange_device(steps, local_images: torch.Tensor):
+    """Where the small tensors that go through a collective live: the steps provider's device (RCCL has no CPU path; CPU-resident
+    images are moved there by the steps anyway)."""
+    return steps.device if hasattr(steps, "device") else local_images.device
+
+
+def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, tiles: list[int]):
     n, _, h, w = local_images.shape
     shape = (int(n), int(h), int(w))
-    dev = steps.device if hasattr(steps, "device") else local_images.device
-    tiles = tiles_per_rank(int(n), dev, group)      # the sample union and the pixel total need them (shapes only, no pixel data)
     size = len(tiles)                                 # (1 when the collectives are skipped)
     n_all = int(sum(tiles)) * int(h) * int(w)
     if n_all >= 1 << 32:
@@ -213,7 +225,7 @@ def reinhard_transform_pooled(local_images: torch.Tensor, reference_mean, refere
         from stainx_amd.backends.torch_hip_backend import ReinhardHIP
 
         steps = ReinhardHIP(device if device is not None else local_images.device)
-    tiles_per_rank(int(local_images.shape[0]), local_images.device if local_images.is_cuda else (device or "cpu"), group)
+    tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
     sums = all_reduce_sum(steps.local_sums(local_images), group)
     pixels = torch.tensor([local_images.shape[0] * local_images.shape[2] * local_images.shape[3]], dtype=torch.int64, device=sums.device)
     n_total = int(all_reduce_sum(pixels, group).item())
@@ -226,7 +238,7 @@ def hm_transform_pooled(local_images: torch.Tensor, reference_histogram, *, grou
         from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
 
         steps = HistogramMatchingHIP(device if device is not None else local_images.device, channel_axis=channel_axis)
-    tiles_per_rank(int(local_images.shape[0]), local_images.device if local_images.is_cuda else (device or "cpu"), group)
+    tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
     counts = all_reduce_sum(steps.local_counts(local_images), group)
     n_total = int(counts[0].sum().item())
     return steps.apply_with_counts(local_images, counts, n_total, reference_histogram)

@@ -182,3 +182,36 @@ class TestTransformValidation:
         t = StainNormalizerTransform(method="reinhard", mode="batch", batch_ref_index=5, device="cpu")
         with pytest.raises(IndexError, match="out of range"):
             t(torch.rand(2, 3, 8, 8))
+
+
+def test_hm_reference_cache_survives_inference_tensors():
+    """the stacked-reference cache read `_version`, which inference tensors do not have (RuntimeError on every transform
+    after a fit under torch.inference_mode()).  Host logic only: the object is built without its device checks."""
+    from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
+
+    be = HistogramMatchingHIP.__new__(HistogramMatchingHIP)
+    be.device = torch.device("cpu")
+    with torch.inference_mode():
+        hists = [torch.full((256,), 1.0 / 256) for _ in range(3)]
+    assert hists[0].is_inference()
+    a = be._stack_reference(hists, 3)
+    b = be._stack_reference(hists, 3)
+    assert a.shape == (3, 256) and torch.equal(a, b) and getattr(be, "_ref_cache", None) is None      # never cached
+    plain = [torch.full((256,), 1.0 / 256) for _ in range(3)]
+    c = be._stack_reference(plain, 3)
+    assert be._stack_reference(plain, 3) is c                                                      # cached while unchanged
+    plain[1].mul_(2.0)
+    d = be._stack_reference(plain, 3)
+    assert d is not c and float(d[1, 0]) == pytest.approx(2.0 / 256)                               # an in-place change is seen
+
+
+def test_force_collectives_flag_is_parsed_and_read_late(monkeypatch):
+    import stainx_amd.distributed as sxd
+
+    monkeypatch.setattr(sxd, "FORCE_COLLECTIVES", None)
+    for value, want in (("", False), ("0", False), ("false", False), ("1", True), ("true", True), ("YES", True)):
+        monkeypatch.setenv("STAINX_FORCE_COLLECTIVES", value)
+        assert sxd.force_collectives() is want, value
+    monkeypatch.setattr(sxd, "FORCE_COLLECTIVES", True)
+    monkeypatch.setenv("STAINX_FORCE_COLLECTIVES", "0")
+    assert sxd.force_collectives() is True

@@ -89,6 +89,7 @@ def _empty_rank_worker(rank: int, world_size: int, port: int, out_dir: str):
         lo, hi = sxd.shard_bounds(1, rank, world_size)
         raised = []
         for call in (lambda: sxd.macenko_fit_pooled(tiles[lo:hi], steps=NumpyMacenkoBracketSteps()),
+                     lambda: sxd.macenko_fit_pooled(tiles[lo:hi], steps=NumpyMacenkoBracketSteps(), method="radix"),      # (the radix form skipped the guard)
                      lambda: sxd.hm_transform_pooled(synth.noise_u8((1, 3, 16, 16), 1)[lo:hi], so.hm_fit(synth.noise_u8((1, 3, 16, 16), 2).numpy()), steps=NumpyHMSteps())):
             try:
                 call()
@@ -128,7 +129,7 @@ def _forced_worker(rank: int, world_size: int, port: int, out_dir: str):
         assert calls["n"] >= 3                                            # ... unless forced (what the one-GPU RCCL test and bench mode use)
         np.savez(os.path.join(out_dir, "forced.npz"), same=bool(torch.equal(plain[0], forced[0]) and torch.equal(plain[1], forced[1])))
     finally:
-        sxd.FORCE_COLLECTIVES = False
+        sxd.FORCE_COLLECTIVES = None
         dist.destroy_process_group()
 
 
