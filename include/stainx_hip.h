@@ -54,6 +54,9 @@ typedef enum {
                                        callers whose batches hold tiles without tissue: see sx_macenko_telemetry_offset) */
 #define SX_MACENKO_TWO_PASS 256u     /* the two-pass form wherever it can run (by default only where it is the faster one: f32 / f64 batches of
                                        >= 4 M pixels, tiles of 128x128 ... 724x724) */
+#define SX_MACENKO_FUSE 512u         /* the two-pass form with its last three launches (pass A, stage, reconstruct) as ONE launch with tile-level
+                                       dependencies, where it can run that way (planar float32 tiles of 128x128 ... 512x512; same bits).  Opt-in:
+                                       measured slower than the four launches on MI355X; kept for A/B runs and tests */
 #define SX_MACENKO_SPEC_FAIL 128u    /* diagnostic: the two-pass form treats every speculation as failed (forces its slow exact path; tests) */
 #define SX_MACENKO_NO_TIE_SHORTCUT 8u /* diagnostic: do not resolve a bracket that closed on one key from its counts (forces the slow exact paths; tests) */
 #define SX_MACENKO_CHANNELS_LAST 2u /* images and output are (N,H,W,3) (decoder / PIL layout) instead of (N,3,H,W); an extension: the
@@ -71,6 +74,11 @@ const char* sx_last_error_string(void);
  *   stain_matrix_dev  6 floats, row-major (3,2)      target_max_conc_dev  2 floats
  */
 size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, int64_t width);
+/* sx_macenko_workspace_bytes() serves ANY sx_macenko_* call on such a batch.  What ONE sx_macenko_transform call with these
+ * arguments needs is a prefix of it and can be much less: the call checks its workspace against THIS size (narrow pixels and
+ * small batches take the four-pass form and none of the two-pass areas; the fused launch does not need the four-launch form's
+ * candidate arrays).  sx_macenko_fit and the sx_macenko_dfit_* and sx_macenko_pfit_* steps need the size of a call with SX_MACENKO_CLASSIC. */
+size_t sx_macenko_workspace_bytes_for(int dtype, int64_t n_tiles, int64_t height, int64_t width, unsigned flags);
 
 int sx_macenko_transform(const void* images_dev, void* out_dev, int dtype, int64_t n_tiles, int64_t height,
                          int64_t width, const float* stain_matrix_dev, const float* target_max_conc_dev,
@@ -87,6 +95,9 @@ size_t sx_macenko_telemetry_offset(void);
 /* 1 if sx_macenko_transform takes its two-pass form for such a call (element type, batch, tile size, flags), 0 for the four-pass
  * form: a host only needs to watch the telemetry word after calls of the first kind. */
 int sx_macenko_takes_two_pass(int dtype, int64_t n_tiles, int64_t height, int64_t width, unsigned flags);
+/* The same in full: 0 four passes, 1 two-pass form as four launches, 2 two-pass form with pass A, the per-tile stages and the
+ * reconstruct pass in one launch (only with SX_MACENKO_FUSE; falls back to 0 at call time when a pointer is not 16-byte aligned). */
+int sx_macenko_form(int dtype, int64_t n_tiles, int64_t height, int64_t width, unsigned flags);
 
 /* Replaces MacenkoTorch.compute_reference_stain_matrix_torch (torch_backend.py:463-519): one stain
  * estimate pooled over all n_tiles*H*W pixels, no "<3 kept pixels" fallback.

@@ -26,6 +26,7 @@ MACENKO_OUT_BF16 = 32
 MACENKO_OUT_F16 = 64
 MACENKO_SPEC_FAIL = 128
 MACENKO_TWO_PASS = 256
+MACENKO_FUSE = 512
 MACENKO_PARAM_FLOATS = 48
 PFIT_SUMS = 1033
 PFIT_COMPACT = 32768
@@ -40,6 +41,8 @@ SIGNATURES = {
     "sx_version": (_int, []),
     "sx_last_error_string": (_c.c_char_p, []),
     "sx_macenko_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "sx_macenko_workspace_bytes_for": (_sz, [_int, _i64, _i64, _i64, _uint]),
+    "sx_macenko_form": (_int, [_int, _i64, _i64, _i64, _uint]),
     "sx_macenko_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _uint, _vp, _sz, _vp]),
     "sx_macenko_fit": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sx_macenko_tile_params": (_int, [_vp, _i64, _vp, _vp]),

@@ -9,6 +9,9 @@ torch_backend.py:463-466) -- there is no torch-op or CPU path in this package.
 """
 from __future__ import annotations
 
+import os
+import threading
+
 import torch
 
 from stainx_amd import _native
@@ -74,7 +77,10 @@ class MacenkoHIP(TorchHIPBackendBase):
         self._classic_span = 32
         self._tele_age = 0
         self._tele_ptr = 0
-        self._tele_base = (0, 0)      # (workspace pointer, the count read there last)
+        self._tele_seen: dict[int, tuple[int, int]] = {}      # workspace pointer -> (slow selections, waits that ran out) read there last
+        self._tele_lock = threading.Lock()                     # (one object may be driven from several threads, each on its own stream)
+        # A/B switch for benchmarks (it used to live inside the library): the four-pass form everywhere
+        self._env_flags = _native.MACENKO_CLASSIC if os.environ.get("STAINX_MACENKO_CLASSIC", "").strip().lower() in ("1", "true", "yes", "on") else 0
 
     @staticmethod
     def _check_images(images: torch.Tensor, what: str) -> None:
@@ -116,29 +122,31 @@ class MacenkoHIP(TorchHIPBackendBase):
         if n == 0 or h * w == 0:
             return out
         with torch.cuda.device(self.device):
-            nbytes = self._lib.sx_macenko_workspace_bytes(n, h, w)
-            ws = self._scratch.get(nbytes, self.device)
             flags = ((_native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0) | (_native.MACENKO_CHANNELS_LAST if channels_last else 0)
-                     | (_native.MACENKO_SAMPLED if self._precision == "sampled" else 0) | int(_extra_flags))
+                     | (_native.MACENKO_SAMPLED if self._precision == "sampled" else 0) | int(_extra_flags) | self._env_flags)
             # (only calls the library would run in its two-pass form take part in the feedback: for the others -- small batches,
             # narrow pixels -- the event, the side-stream copy and the stream bookkeeping are 7 us of host time per call for nothing)
             routed = (not (flags & (_native.MACENKO_CLASSIC | _native.MACENKO_TWO_PASS | _native.MACENKO_SAMPLED))
                       and self._lib.sx_macenko_takes_two_pass(code, n, h, w, flags) == 1)
+            # the workspace of the form the library WOULD take: a routed call may be sent to the four-pass form below, whose
+            # workspace is a prefix of it (one buffer per stream serves both)
+            nbytes = self._lib.sx_macenko_workspace_bytes_for(code, n, h, w, flags)
+            ws = self._scratch.get(nbytes, self.device)
             if routed:
-                if self._tele_base[0] != ws.data_ptr() and not torch.cuda.is_current_stream_capturing():
-                    # a workspace seen for the first time (first call, or the scratch grew): where its running count stands
-                    self._tele_base = (ws.data_ptr(), int(ws[self._tele_offset:self._tele_offset + 4].view(torch.int32).item()) & 0xFFFFFFFF)
-                flags |= self._route()
+                with self._tele_lock:
+                    flags |= self._route()
             rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),
                                                 flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
             _native.check(rc, "sx_macenko_transform")
             if routed and not (flags & _native.MACENKO_CLASSIC):
-                self._watch(ws)
+                with self._tele_lock:
+                    self._watch(ws)
         self.last_workspace = ws
         return out
 
     def _route(self) -> int:
-        """Flag for this call: the four-pass form while a recent call reported tiles the two-pass form could not speculate on."""
+        """Flag for this call: the four-pass form while a recent call reported tiles the two-pass form could not speculate on.
+        Never synchronises the host with the device except to wait for an answer that is five calls old (see below)."""
         if torch.cuda.is_current_stream_capturing():
             return _native.MACENKO_CLASSIC      # a captured call is replayed on data nobody has seen: the form without a cliff (and no event may be queried here)
         if self._tele_event is not None:
@@ -150,13 +158,17 @@ class MacenkoHIP(TorchHIPBackendBase):
                 # waited for: the device does not run dry.
                 self._tele_event.synchronize()
         if self._tele_event is not None and self._tele_event.query():
-            # a running count (the library only adds to it): what is new since the last look at this workspace; the first look at a
-            # workspace only sets the base (fresh memory holds anything)
-            now = int(self._tele_host[0]) & 0xFFFFFFFF
-            slow = ((now - self._tele_base[1]) & 0xFFFFFFFF) if self._tele_base[0] == self._tele_ptr else 0
-            if self._tele_base[0] == self._tele_ptr:
-                self._tele_base = (self._tele_ptr, now)
+            # running counts (the library only adds to them): what is new since the last look at THIS workspace.  The first look
+            # at a workspace only sets its base (fresh memory holds anything) -- taken from this same asynchronous read-back, so
+            # a call on a new stream or a grown scratch costs no host synchronisation.
+            now = (int(self._tele_host[0]) & 0xFFFFFFFF, int(self._tele_host[1]) & 0xFFFFFFFF)
+            seen = self._tele_seen.get(self._tele_ptr)
+            self._tele_seen[self._tele_ptr] = now
             self._tele_event = None
+            slow = ((now[0] - seen[0]) & 0xFFFFFFFF) if seen is not None else 0
+            if seen is not None and ((now[1] - seen[1]) & 0xFFFFFFFF) != 0:
+                raise RuntimeError("sx_macenko_transform: a bounded wait inside the fused launch ran out on an earlier call (the device did not run its "
+                                   "workgroups to completion); that call's output is incomplete")
             if slow > 0:
                 self._classic_left = self._classic_span
                 self._classic_span = min(self._classic_span * 2, 4096)      # probe again, less and less often
@@ -168,18 +180,18 @@ class MacenkoHIP(TorchHIPBackendBase):
         return 0
 
     def _watch(self, ws: torch.Tensor) -> None:
-        """Read the library's count of slow selections back without making anything wait: a side stream copies four bytes once the
-        call's kernels are done.  (Not inside a stream capture; advisory only -- a later call may have reset the word already.)"""
+        """Read the library's counts of slow selections (and of waits that ran out) back without making anything wait: a side stream
+        copies eight bytes once the call's kernels are done.  (Not inside a stream capture; advisory only.)"""
         if self._tele_event is not None or torch.cuda.is_current_stream_capturing():
             return
         if self._tele_host is None:
-            self._tele_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._tele_host = torch.zeros(2, dtype=torch.int32).pin_memory()
             self._tele_stream = torch.cuda.Stream(self.device)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         self._tele_stream.wait_event(done)
         with torch.cuda.stream(self._tele_stream):
-            self._tele_host.copy_(ws[self._tele_offset:self._tele_offset + 4].view(torch.int32), non_blocking=True)
+            self._tele_host.copy_(ws[self._tele_offset:self._tele_offset + 8].view(torch.int32), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._tele_stream)
         ws.record_stream(self._tele_stream)
@@ -197,7 +209,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
         max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            nbytes = self._lib.sx_macenko_workspace_bytes(n, h, w)
+            nbytes = self._lib.sx_macenko_workspace_bytes_for(_dtype_code(images), n, h, w, _native.MACENKO_CLASSIC)
             ws = self._scratch.get(nbytes, self.device)
             rc = self._lib.sx_macenko_fit(images.data_ptr(), _dtype_code(images), n, h, w, he.data_ptr(), max_c.data_ptr(),
                                           ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -217,7 +229,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         n, _, h, w = images.shape
         mom = torch.empty(20, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
-            ws = self._scratch.get(self._lib.sx_macenko_workspace_bytes(n, h, w), self.device)
+            ws = self._scratch.get(self._lib.sx_macenko_workspace_bytes_for(_dtype_code(images), n, h, w, _native.MACENKO_CLASSIC), self.device)
             rc = self._lib.sx_macenko_dfit_moments(images.data_ptr(), _dtype_code(images), n, h, w, mom.data_ptr(), ws.data_ptr(), ws.numel(),
                                                    _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_dfit_moments")
@@ -257,7 +269,7 @@ class MacenkoHIP(TorchHIPBackendBase):
 
     # ---- the same pooled fit across ranks on the bracket machinery (three passes; see stainx_amd/distributed.py) ----
     def _pfit_ws(self, n: int, h: int, w: int) -> torch.Tensor:
-        return self._scratch.get(self._lib.sx_macenko_workspace_bytes(n, h, w), self.device)
+        return self._scratch.get(self._lib.sx_macenko_workspace_bytes_for(_native.DTYPE_CODES[torch.float32], n, h, w, _native.MACENKO_CLASSIC), self.device)
 
     def pfit_sample_count(self, n: int, h: int, w: int) -> int:
         return int(self._lib.sx_macenko_pfit_sample_count(n, h, w))

@@ -31,7 +31,7 @@ namespace sx {
 namespace macenko {
 
 constexpr int kSample = 4096;          // strided sample per tile
-constexpr int kMinCap = 32768;         // candidate keys per selection slot: at least this, 1/16 of the group's pixels for big groups
+constexpr int kMinCap = 8192;          // candidate keys per selection slot: at least this (what the per-tile stages request up front); see cap_for()
 constexpr int kChunk = 16384;          // pixels per work item (64 per lane of a 256-thread workgroup)
 template <typename T> struct PackOf { static constexpr int n = 16 / (int)sizeof(T); };   // pixels per 16-byte load: f32 4, bf16/f16 8, u8 16, f64 2
 constexpr int kSlots = 4;              // 0: phi@1  1: phi@99  2: C0@99  3: C1@99
@@ -81,6 +81,8 @@ struct alignas(256) GroupState {
     uint32_t over_count[kSlots];  // two-pass transform: candidates of the tile that did not fit their wave's segment (overflow area fill)
     uint32_t slow_slots;          // two-pass transform, tile 0 only: a RUNNING count of selections that left the speculative path (telemetry: only ever added to,
                                   // so that a host that reads it late -- the next call's kernels may already be running -- still sees what happened)
+    uint32_t spin_timeouts;       // fused transform, tile 0 only, directly behind slow_slots: a RUNNING count of bounded waits that ran out (the call's
+                                  // output is then incomplete; never observed -- the host reads it with the telemetry and raises)
     unsigned long long stamp[16]; // diagnostic: wall_clock64() at stage boundaries of the per-tile stages
 };
 
@@ -109,6 +111,10 @@ struct Geometry {
     uint32_t over_cap;            // two-pass: ... and the tile's overflow area behind the segments holds this many
     int n_seg;                    // two-pass: segments per tile = waves of pass A per tile
     int spec_fail;                // diagnostic (SX_MACENKO_SPEC_FAIL): treat every speculation as failed -> the slow exact path
+    float spec_kw, spec_eff_far, spec_eff_near, spec_rot, spec_sigmas;      // two-pass: the speculation's knobs (macenko_twopass.hpp: kSpecKw ...)
+    int fused;                    // two-pass: pass A, the per-tile stages and the reconstruct pass in ONE launch (macenko_fused.hpp)
+    uint32_t fused_cap;           // fused: candidate records per tile and slot
+    int fused_items;              // fused: pass-A work items of the call (= reconstruct work items)
 };
 
 // Every field named: the struct is filled at half a dozen entry points.
@@ -152,6 +158,9 @@ struct Workspace {
     float* cand_od;               // two-pass transform: [n_tiles][kSlots][3][cap2] optical density of the candidates
     uint32_t* seg_count;          // two-pass transform: [n_tiles][kSlots][n_seg] candidates each wave of pass A produced
     uint32_t* key_spill;          // two-pass transform: [n_tiles][kSlots][cap2 - kLdsKeys] keys of a slot beyond the stages' LDS array (big tiles)
+    struct FusedSched* fsched;    // fused transform: the launch's ticket counter and error word
+    struct FusedTile* ftile;      // fused transform: per tile, the counters the roles of the launch hand each other work through
+    uint4* cand_rec;              // fused transform: [n_tiles][kSlots][fused_cap] candidate records (od0, od1, od2, -)
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -160,7 +169,10 @@ static int blocks_per_tile_for(int64_t pixels) { return (int)((pixels + kChunk -
 
 // Candidate capacity per slot of a group of `count` pixels: brackets hold ~2-3 % of the pixels.
 static uint32_t cap_for(int64_t count) {
+    // 1/8 of a small group's pixels (a 224 x 224 tile: 8192 keys per slot, not the 32768 that made a 256-tile bf16 batch's
+    // workspace four times the batch), 32768 from 256 x 256 on, 1/16 of the pixels for big groups
     int64_t cap = kMinCap;
+    while (cap < count / 8 && cap < 32768) cap *= 2;
     while (cap < count / 16) cap *= 2;
     return (uint32_t)cap;
 }
@@ -186,7 +198,19 @@ static uint32_t cap2_for(int64_t pixels) { return (uint32_t)((int64_t)two_pass_s
 static size_t key_spill_words(int64_t pixels) { return cap2_for(pixels) > (uint32_t)kLdsKeys ? (size_t)cap2_for(pixels) - kLdsKeys : 0; }      // keys of a slot beyond the stages' LDS array
 static bool two_pass_size(int64_t pixels) { return pixels >= 256 && pixels <= 64ll * kChunk; }      // (at most 256 waves of pass A per tile)
 
-static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
+// Fused transform (macenko_fused.hpp): which tile sizes take it, and its candidate records per tile and slot
+constexpr uint32_t kFusedCapMax = 14336;      // (256 threads x 32 keys in registers + 6144 keys in LDS: macenko_fused.hpp)
+static bool fused_size(int64_t pixels) { return pixels >= 16384 && pixels <= 262144 && pixels % 4 == 0; }
+static uint32_t fused_cap_for(int64_t pixels) { return (uint32_t)std::min<int64_t>(kFusedCapMax, std::max<int64_t>(2048, (pixels / 4 + 255) / 256 * 256)); }
+constexpr size_t kFusedSchedBytes = 512, kFusedTileBytes = 64;
+
+// The workspace is laid out so that what a form of the transform needs is a PREFIX of the whole:
+//   [ base: state, partial sums, classic candidates, histograms, sample, pool ]   every entry point
+//   [ prior records | fused: schedule, per-tile counters, candidate records ]      + the fused two-pass transform
+//   [ two-pass: candidate optical densities, segment fills, key spill ]            + the four-launch two-pass transform
+// sx_macenko_workspace_bytes() is the whole (any call fits); sx_macenko_workspace_bytes_for() the prefix one call needs.
+enum WorkspaceLevel { kWsBase = 0, kWsFused = 1, kWsTwoPass = 2 };
+static size_t workspace_bytes(int64_t n_tiles, int64_t pixels, int level = kWsTwoPass) {
     const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
     size_t total = align_up(sizeof(GroupState) * n, 256);
     total += 2 * align_up(sizeof(double) * kPartial * b * n, 256);
@@ -194,8 +218,13 @@ static size_t workspace_bytes(int64_t n_tiles, int64_t pixels) {
     total += align_up(sizeof(uint32_t) * 512 * b * n, 256);
     total += align_up(sizeof(float) * 3 * kSample * n, 256);
     total += align_up(sizeof(PoolState), 256);
-    if (two_pass_size(pixels)) {
+    if (level >= kWsFused && two_pass_size(pixels)) {
         total += align_up(kPriorRecordBytes * n, 256);
+        total += kFusedSchedBytes;
+        total += align_up(kFusedTileBytes * n, 256);
+        if (fused_size(pixels)) total += align_up(sizeof(uint4) * kSlots * (size_t)fused_cap_for(pixels) * n, 256);
+    }
+    if (level >= kWsTwoPass && two_pass_size(pixels)) {
         total += align_up(sizeof(float) * 3 * kSlots * (size_t)cap2_for(pixels) * n, 256);
         total += align_up(sizeof(uint32_t) * kSlots * 256 * n, 256);
         total += align_up(sizeof(uint32_t) * kSlots * key_spill_words(pixels) * n, 256);
@@ -221,8 +250,15 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     p += align_up(sizeof(float) * 3 * kSample * n, 256);
     w.pool = reinterpret_cast<PoolState*>(p);
     p += align_up(sizeof(PoolState), 256);
+    // (beyond the base level the pointers are only used by the forms whose workspace level includes them)
     w.prior = reinterpret_cast<PriorRecord*>(p);
     p += align_up(kPriorRecordBytes * n, 256);
+    w.fsched = reinterpret_cast<FusedSched*>(p);
+    p += kFusedSchedBytes;
+    w.ftile = reinterpret_cast<FusedTile*>(p);
+    p += align_up(kFusedTileBytes * n, 256);
+    w.cand_rec = reinterpret_cast<uint4*>(p);
+    if (fused_size(pixels)) p += align_up(sizeof(uint4) * kSlots * (size_t)fused_cap_for(pixels) * n, 256);
     w.cand_od = reinterpret_cast<float*>(p);
     p += align_up(sizeof(float) * 3 * kSlots * (size_t)cap2_for(pixels) * n, 256);
     w.seg_count = reinterpret_cast<uint32_t*>(p);
@@ -239,7 +275,16 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
 template <typename U> __device__ __forceinline__ void put(U* p, U v) { *p = v; }
 template <typename U> __device__ __forceinline__ U get(const U* p) { return *p; }
 
+// Diagnostic time stamps of the per-tile stages (tools/bench_twopass.py, tools/stage_stamps.py) and of the fused launch's units
+// (tools/fused_timeline.py): compiled in only with -DSX_STAMPS (tools/build_debug.sh -> libstainx_dbg.so); the product build
+// carries none of them (sx_macenko_tile_params then reports zeros in its stamp slots).
+#ifdef SX_STAMPS
 #define SX_STAMP(st, i) do { if (threadIdx.x == 0) (st).stamp[i] = (unsigned long long)wall_clock64(); } while (0)
+#define SX_UNIT_STAMP(ws, unit, i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>((ws).block_hist)[(size_t)(unit) * 8 + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define SX_STAMP(st, i) do { } while (0)
+#define SX_UNIT_STAMP(ws, unit, i) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // per-pixel arithmetic
@@ -901,8 +946,8 @@ __device__ __forceinline__ void reset_scratch(TileScratch* sh) {
 
 // Exact rank-th smallest (0-based) of the valid keys produced by key_at(i), i in [0,count): four 8-bit radix
 // rounds, keys recomputed/re-read in every round.  Slow path, whole workgroup.
-template <class KeyAt>
-__device__ uint32_t radix_select_stream(unsigned long long count, unsigned long long rank, KeyAt key_at, TileScratch* sh) {
+template <class KeyAt, class Scratch>
+__device__ uint32_t radix_select_stream(unsigned long long count, unsigned long long rank, KeyAt key_at, Scratch* sh) {
     uint32_t prefix = 0, mask = 0;
     __syncthreads();
     if (threadIdx.x == 0) sh->radix_rank = rank;
@@ -1464,14 +1509,26 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 // streaming stage S4: concentrations -> rescale -> reconstruct -> clamp -> cast  (torch_backend.py:452-461,560)
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename O, int V, bool kUnit, int TPB, bool kInter>
-__device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
-                                 const float* __restrict__ stain_matrix, const LevelTables<T>& tb, uint4* __restrict__ stage = nullptr) {
+__device__ __forceinline__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
+                                 const float* __restrict__ stain_matrix, const LevelTables<T>& tb, uint4* __restrict__ stage = nullptr, const float* __restrict__ given = nullptr) {
     const int64_t chunk = g.fine_chunk ? g.fine_chunk : g.chunk;
     const int64_t p_begin = (int64_t)chunk_id * chunk;
     const int64_t p_end = min(p_begin + chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
     O* dst = out + tile * 3 * g.pixels;
-    const StageRecord* rec = &ws.state[tile].rec[2];
+    // the tile's pseudo-inverse (6) and scale (2): the stage record of the launch before this one, or (fused transform) what the
+    // caller has read from the stage job of the same launch
+    float rec8[8];
+    if (given) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rec8[i] = given[i];
+    } else {
+        const StageRecord* rec = &ws.state[tile].rec[2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rec8[i] = get(&rec->coef[i]);
+        rec8[6] = get(&rec->scale[0]);
+        rec8[7] = get(&rec->scale[1]);
+    }
 
     // The whole chain OD -> C = pinv OD -> C * (tmc/maxC) -> SM C -> 240 exp(-.) (torch_backend.py:444-458) is linear between
     // the logarithm and the exponential, so it is folded into one 3x3 matrix per tile (fp64, then fp32):
@@ -1483,10 +1540,10 @@ __device__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ o
         double pinv[6], sm[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            pinv[i] = (double)get(&rec->coef[i]);
+            pinv[i] = (double)rec8[i];
             sm[i] = (double)stain_matrix[i];
         }
-        const double s0 = (double)get(&rec->scale[0]), s1 = (double)get(&rec->scale[1]);
+        const double s0 = (double)rec8[6], s1 = (double)rec8[7];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double row = 0.0;
@@ -1751,9 +1808,9 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
 // ------------------------------------------------------------------------------------------------
 // exact order statistics of the two slots of a stage from what the streaming stage left behind
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, class Scratch>
 __device__ uint32_t select_whole_group(const T* __restrict__ images, const Geometry& g, int group, int slot, unsigned long long rank, const float* coef, bool use_all,
-                                       TileScratch* sh) {
+                                       Scratch* sh) {
     const GroupPixels gp = group_pixels(g, group);
     return radix_select_stream((unsigned long long)gp.count, rank,
                                [&](unsigned long long i, uint32_t& k) {
@@ -2419,6 +2476,7 @@ __global__ void export_params_kernel(const GroupState* __restrict__ state, int64
 }  // namespace macenko
 }  // namespace sx
 #include "macenko_twopass.hpp"
+#include "macenko_fused.hpp"
 namespace sx {
 namespace macenko {
 static_assert(sizeof(PriorRecord) == kPriorRecordBytes, "workspace layout");
@@ -2487,6 +2545,18 @@ static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws,
     return check_launch("macenko two-pass estimate");
 }
 
+// The fused two-pass transform (macenko_fused.hpp): the prior, then pass A + stage jobs + reconstruct items in ONE launch.
+template <typename T, typename O, int V>
+static int run_fused(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
+    const unsigned n = (unsigned)g.n_tiles, units = (unsigned)(2 * g.fused_items) + 2u * n;
+    hipLaunchKernelGGL((prior_kernel<T, true, false>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
+    if (unit)
+        hipLaunchKernelGGL((fused_kernel<T, O, V, true>), dim3(units), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm, tmc);
+    else
+        hipLaunchKernelGGL((fused_kernel<T, O, V, false>), dim3(units), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm, tmc);
+    return check_launch("macenko fused transform");
+}
+
 template <typename T, typename O, int V, bool kInter = false>
 static int run_transform(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
     const unsigned items = (unsigned)(g.n_tiles * (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile));
@@ -2524,7 +2594,26 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     g.vec = vec ? 1 : 0;
     g.vec_width = W;
     set_sampling(g);
+    if (g.fused && !(vec && !g.interleaved && !u8_half && std::is_same<T, float>::value)) {      // (unaligned pointers: the four-pass form serves them; its workspace is a prefix of the fused one)
+        g.fused = 0;
+        g.two_pass = 0;
+    }
     if (g.two_pass) {
+        g.spec_kw = kSpecKw;
+        g.spec_eff_far = kSpecEffFar;
+        g.spec_eff_near = kSpecEffNear;
+        g.spec_rot = kSpecRot;
+        g.spec_sigmas = kSpecSigmas;
+#ifdef SX_STAMPS      // diagnostic builds only: the knobs from the environment (tools/sweep_real.py under tools/tune_spec.sh)
+        auto knob = [](const char* name, float& v) { if (const char* e = std::getenv(name)) v = (float)std::atof(e); };
+        knob("SX_SPEC_KW", g.spec_kw);
+        knob("SX_SPEC_EFF_FAR", g.spec_eff_far);
+        knob("SX_SPEC_EFF_NEAR", g.spec_eff_near);
+        knob("SX_SPEC_ROT", g.spec_rot);
+        knob("SX_SPEC_SIGMAS", g.spec_sigmas);
+#endif
+        g.fused_cap = fused_cap_for(g.pixels);
+        g.fused_items = (int)(g.n_tiles * g.blocks_per_tile);
         g.cap2 = cap2_for(g.pixels);
         g.n_seg = two_pass_segments(g.pixels);
         g.seg_cap = seg_cap_for(g.pixels);
@@ -2538,7 +2627,7 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     // change a bit of the result) then use smaller work items -- at least two sweeps of a workgroup, aiming at ~1024 work
     // items; the moments stage keeps its fixed 16384-pixel grouping so that a tile's covariance has the same bits
     // whatever batch it arrives in.
-    if (g.n_tiles * (int64_t)g.blocks_per_tile <= 32) {      // (measured: 1 tile 89 -> 78 us, 2 tiles 90 -> 81 us; from 4 tiles on the fixed cost per work item eats the gain)
+    if (g.n_tiles * (int64_t)g.blocks_per_tile <= 32 && !g.fused) {      // (the fused launch's reconstruct items are its pass-A items) (measured: 1 tile 89 -> 78 us, 2 tiles 90 -> 81 us; from 4 tiles on the fixed cost per work item eats the gain)
         const int64_t floor_px = (int64_t)kStreamThreads * (vec ? W : 1) * 2;
         int64_t chunk = 2048;
         while (chunk < floor_px) chunk *= 2;
@@ -2579,6 +2668,9 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
             return vec ? run_transform<T, float, W>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream)
                        : run_transform<T, float, 1>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream);
         }
+    }
+    if constexpr (std::is_same<T, float>::value) {
+        if (g.fused) return run_fused<T, T, W>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream);
     }
     return vec ? run_transform<T, T, W>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream)
                : run_transform<T, T, 1>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream);
@@ -2764,21 +2856,34 @@ extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, in
     return macenko::workspace_bytes(n_tiles, height * width);
 }
 
-// Which form sx_macenko_transform takes for a call (1: two-pass).  Where the two-pass form pays (measured, tools/bench_twopass.py):
-// 4- and 8-byte pixels in batches of at least ~4 M pixels and tiles up to ~724 x 724.  Narrow pixels (uint8 / bf16 / f16) make the
-// four passes cheap -- the two forms are level there (120 vs 123 us, 128 vs 132 us) --, big tiles put tens of thousands of
-// candidates on one stage workgroup.  SX_MACENKO_TWO_PASS asks for it wherever it is able to run (tests, A/B runs).
-extern "C" int sx_macenko_takes_two_pass(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) {
-    static const bool env_classic = std::getenv("STAINX_MACENKO_CLASSIC") != nullptr;      // A/B switch for benchmarks
+// Which form sx_macenko_transform takes for a call: 0 the four passes, 1 the two-pass form as four launches, 2 the two-pass form
+// with pass A, the stage jobs and the reconstruct pass fused into one launch.  Where the two-pass form pays (measured,
+// tools/bench_twopass.py): 4- and 8-byte pixels in batches of at least ~4 M pixels and tiles up to ~724 x 724.  Narrow pixels
+// (uint8 / bf16 / f16) make the four passes cheap -- the forms are level there --, big tiles put tens of thousands of candidates on
+// one stage workgroup.  The fused launch serves planar float32 tiles of 128 x 128 ... 512 x 512 pixels.  SX_MACENKO_TWO_PASS asks
+// for the two-pass form wherever it is able to run (tests, A/B runs); SX_MACENKO_NO_FUSE keeps it to four launches.
+extern "C" int sx_macenko_form(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) {
     if (n <= 0 || h <= 0 || w <= 0 || (flags & SX_MACENKO_SAMPLED)) return 0;
     const int64_t pixels = h * w;
     const bool pays = (dtype == SX_F32 || dtype == SX_F64) && pixels >= 16384 && pixels <= (1ll << 19) && n * pixels >= (1ll << 22);
-    const bool wanted = (flags & SX_MACENKO_TWO_PASS) != 0 || (pays && !(flags & SX_MACENKO_CLASSIC) && !env_classic);
-    return (wanted && two_pass_size(pixels)) ? 1 : 0;
+    const bool wanted = (flags & SX_MACENKO_TWO_PASS) != 0 || (pays && !(flags & SX_MACENKO_CLASSIC));
+    if (!(wanted && two_pass_size(pixels))) return 0;
+    const bool fusable = (flags & SX_MACENKO_FUSE) != 0 && dtype == SX_F32 && fused_size(pixels) && !(flags & SX_MACENKO_CHANNELS_LAST);
+    return fusable ? 2 : 1;
+}
+extern "C" int sx_macenko_takes_two_pass(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) { return sx_macenko_form(dtype, n, h, w, flags) != 0 ? 1 : 0; }
+
+// The part of the workspace ONE call of sx_macenko_transform with these arguments needs (a prefix of sx_macenko_workspace_bytes(),
+// which serves any call): without the two-pass areas where the call takes the four-pass form (narrow pixels, small batches), and
+// without the four-launch form's candidate arrays where it takes the fused launch.
+extern "C" size_t sx_macenko_workspace_bytes_for(int dtype, int64_t n_tiles, int64_t height, int64_t width, unsigned flags) {
+    if (n_tiles <= 0 || height <= 0 || width <= 0) return 0;
+    const int form = sx_macenko_form(dtype, n_tiles, height, width, flags);
+    return macenko::workspace_bytes(n_tiles, height * width, form == 2 ? kWsFused : (form == 1 ? kWsTwoPass : kWsBase));
 }
 
 extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* sm, const float* tmc, unsigned flags, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
-    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes_for(dtype, n, h, w, flags));
     if (rc != SX_OK) return rc;
     if (!out || !sm || !tmc) return fail(SX_ERR_BAD_ARG, "out / stain_matrix / target_max_conc pointer is null");
     if ((flags & (SX_MACENKO_OUT_BF16 | SX_MACENKO_OUT_F16)) != 0 && (dtype != SX_U8 || (flags & SX_MACENKO_OUT_BF16 && flags & SX_MACENKO_OUT_F16)))
@@ -2789,7 +2894,9 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     g.no_tie = (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0;
     g.out_code = (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0);
     g.spec_fail = (flags & SX_MACENKO_SPEC_FAIL) ? 1 : 0;
-    g.two_pass = sx_macenko_takes_two_pass(dtype, n, h, w, flags);
+    const int form = sx_macenko_form(dtype, n, h, w, flags);
+    g.two_pass = form != 0 ? 1 : 0;
+    g.fused = form == 2 ? 1 : 0;
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
@@ -2804,7 +2911,7 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
 }
 
 extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t h, int64_t w, float* he_out, float* max_c_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
-    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes_for(dtype, n, h, w, SX_MACENKO_CLASSIC));
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
     Geometry g = make_geometry(n, h * w, 1);
@@ -2828,12 +2935,20 @@ extern "C" int sx_macenko_tile_params(const void* ws_ptr, int64_t n_groups, floa
     return check_launch("macenko export_params");
 }
 
+#ifdef SX_STAMPS
+// (debug builds only, not part of the ABI) where the fused launch's unit stamps lie: eight uint64 per unit (blockIdx) in the block-histogram area
+extern "C" size_t sx_debug_unit_stamp_offset(int64_t n, int64_t h, int64_t w) {
+    const Workspace ws = carve(nullptr, n, h * w);
+    return (size_t)reinterpret_cast<uintptr_t>(ws.block_hist);
+}
+#endif
+
 extern "C" size_t sx_macenko_telemetry_offset(void) { return offsetof(GroupState, slow_slots); }
 
 extern "C" size_t sx_macenko_dfit_state_bytes(void) { return sizeof(DFitState); }
 
 extern "C" int sx_macenko_dfit_moments(const void* images, int dtype, int64_t n, int64_t h, int64_t w, double* moments_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
-    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, macenko::workspace_bytes(n, h * w, kWsBase));
     if (rc != SX_OK) return rc;
     if (!moments_out) return fail(SX_ERR_BAD_ARG, "moments_out pointer is null");
     Geometry g = make_geometry(n, h * w, 1);
@@ -2905,7 +3020,7 @@ extern "C" int sx_macenko_pfit_sample_count(int64_t n, int64_t h, int64_t w) {
 }
 
 extern "C" int sx_macenko_pfit_stats(const void* images, int dtype, int64_t n, int64_t h, int64_t w, double* moments_out, float* sample_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
-    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, macenko::workspace_bytes(n, h * w, kWsBase));
     if (rc != SX_OK) return rc;
     if (!moments_out || !sample_out) return fail(SX_ERR_BAD_ARG, "moments_out / sample_out pointer is null");
     const Geometry g = pfit_geometry(n, h, w, 0, -1);
@@ -2927,7 +3042,7 @@ extern "C" int sx_macenko_pfit_stats(const void* images, int dtype, int64_t n, i
 extern "C" int sx_macenko_pfit_plane(const double* moments, long long n_all, const float* sample_union, int sample_count, int64_t n, int64_t h, int64_t w, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
     if (!moments || !sample_union || !ws_ptr) return fail(SX_ERR_BAD_ARG, "moments / sample_union / workspace pointer is null");
     if (n <= 0 || h <= 0 || w <= 0 || n_all <= 0 || sample_count < 0 || sample_count > kSample) return fail(SX_ERR_BAD_ARG, "bad sizes");
-    if (ws_bytes < sx_macenko_workspace_bytes(n, h, w)) return fail(SX_ERR_WORKSPACE, "workspace too small");
+    if (ws_bytes < macenko::workspace_bytes(n, h * w, kWsBase)) return fail(SX_ERR_WORKSPACE, "workspace too small");
     const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
@@ -2937,7 +3052,7 @@ extern "C" int sx_macenko_pfit_plane(const double* moments, long long n_all, con
 }
 
 extern "C" int sx_macenko_pfit_pass(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int stage, long long n_all, int sample_count, long long* sums_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
-    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, sx_macenko_workspace_bytes(n, h, w));
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, macenko::workspace_bytes(n, h * w, kWsBase));
     if (rc != SX_OK) return rc;
     if (!sums_out || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "sums_out is null or stage is not 0/1");
     const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
@@ -2956,7 +3071,7 @@ extern "C" int sx_macenko_pfit_pass(const void* images, int dtype, int64_t n, in
 extern "C" int sx_macenko_pfit_gather(const long long* sums_global, int stage, long long n_all, int sample_count, int64_t n, int64_t h, int64_t w, int share, unsigned* compact_out, int* counts_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
     if (share < 1 || share > kCompact) return fail(SX_ERR_BAD_ARG, "share must be in [1, %d]", kCompact);
     if (!sums_global || !compact_out || !counts_out || !ws_ptr || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "null pointer or bad stage");
-    if (n <= 0 || h <= 0 || w <= 0 || ws_bytes < sx_macenko_workspace_bytes(n, h, w)) return fail(SX_ERR_WORKSPACE, "bad sizes or workspace too small");
+    if (n <= 0 || h <= 0 || w <= 0 || ws_bytes < macenko::workspace_bytes(n, h * w, kWsBase)) return fail(SX_ERR_WORKSPACE, "bad sizes or workspace too small");
     const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
@@ -2970,7 +3085,7 @@ extern "C" int sx_macenko_pfit_finish(const unsigned* gathered_compact, const in
                                       float* he_out, float* max_c_out, int* status_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
     if (!gathered_compact || !gathered_counts || !ws_ptr || (stage != 0 && stage != 1) || world < 1 || world > 64) return fail(SX_ERR_BAD_ARG, "null pointer, bad stage or world size");
     if (stage == 1 && (!he_out || !max_c_out || !status_out)) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out / status_out pointer is null");
-    if (n <= 0 || h <= 0 || w <= 0 || ws_bytes < sx_macenko_workspace_bytes(n, h, w)) return fail(SX_ERR_WORKSPACE, "bad sizes or workspace too small");
+    if (n <= 0 || h <= 0 || w <= 0 || ws_bytes < macenko::workspace_bytes(n, h * w, kWsBase)) return fail(SX_ERR_WORKSPACE, "bad sizes or workspace too small");
     if (share < 1 || (long long)world * share > kCompact) return fail(SX_ERR_BAD_ARG, "world x share = %d x %d exceeds the compact list (%d)", world, share, kCompact);
     const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
     const Workspace ws = carve(ws_ptr, n, g.pixels);

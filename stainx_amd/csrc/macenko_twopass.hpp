@@ -49,9 +49,11 @@ constexpr float kSpecSigmas = 5.0f;                   // half-width of a bracket
 // the random stress lose no slot to it even at three, tools/sweep_cones.py; small tiles, where the sampled sectors are each other's
 // neighbours, lose a few at two and keep ONE).  A wrong guess costs time only: the slot's proof fails, the slow exact path runs,
 // and the host routes the next calls to the four-pass form.
+// (the values travel in Geometry::spec_*: set by the host from the constants below -- diagnostic builds read overrides from the environment)
 constexpr float kSpecEffFar = 2.0f, kSpecEffNear = 1.0f;
-__device__ __forceinline__ float spec_eff(const Geometry& g) { return g.prior_step_q16 >= (8u << 16) ? kSpecEffFar : kSpecEffNear; }
+__device__ __forceinline__ float spec_eff(const Geometry& g) { return g.prior_step_q16 >= (8u << 16) ? g.spec_eff_far : g.spec_eff_near; }
 constexpr float kSpecKw = 0.05f, kSpecKx = 1.3e-3f;   // margin m = kw |w| + kx |od|_1 + 1e-6 (kx: the fp16 rounding of the pixel, 2^-10, with room)
+constexpr float kSpecRot = 0.04f;                     // largest in-plane rotation |r01| + |r10| between the prior frame and the exact plane a proof accepts
 constexpr uint32_t kSpecSlow = 1u, kSpecHazard = 2u;  // GroupState::spec bits
 constexpr int kMaxSegments = 256;                      // waves of pass A per tile (two_pass_size() keeps tiles within 64 work items)
 
@@ -73,6 +75,42 @@ struct alignas(128) PriorRecord {
     int32_t min_first;
     uint32_t open;                 // bit i: angle boundary i is open (nothing is excluded on that side)
 };
+
+// ---- fused transform (macenko_fused.hpp): what its roles hand each other inside ONE launch -------------------------------
+// Every word below is zeroed by prior_kernel (the launch before), written with agent-scope atomics or write-through (sc1)
+// stores and read with agent-scope (sc1) loads: MI355X_MICROARCH.md, "Valid forms".
+struct alignas(64) FusedTile {
+    uint32_t a_done;             // pass-A work items of the tile that have published their moments and candidates
+    uint32_t s_done;             // stage jobs of the tile that have published their part of the stage record (2 = complete)
+    uint32_t ncand[kSlots];      // candidate records reserved per slot (beyond fused_cap: overflow, the slot takes the slow path)
+    uint32_t pad[10];
+};
+constexpr int kXcds = 8;
+struct alignas(64) FusedQueue {
+    uint32_t ticket;             // next unit of this queue (units are handed out in dependency order)
+    uint32_t pad[15];
+};
+struct FusedSched {
+    FusedQueue queue[kXcds];     // one queue per XCD, each on a line of its own: a single ticket word hands out ~88 units per
+};                               // microsecond, and the launch starts with a thousand workgroups asking at once
+static_assert(sizeof(FusedTile) == kFusedTileBytes && sizeof(FusedSched) <= kFusedSchedBytes, "workspace layout");
+
+
+typedef unsigned int sx_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every storing wave, after its last write-through store and before the barrier in front of the signalling lane (inline asm: the
+// compiler drops a builtin wait it can prove redundant -- MI355X_MICROARCH.md, "Compiler hazard")
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 constexpr int kPriorBins = 2048;       // fixed-range histograms of the prior stage
 constexpr float kOpenExponent = 30.0f;  // an open bracket side's stand-in direction lies w bracket widths beyond the sample extreme, w in [1/4, 1] such that
@@ -175,6 +213,8 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         put(&st.over_count[tid], 0u);
     }
     if (tid < 2) put(&st.phi_pub[tid], 0ull);
+    if (g.fused && tid < (int)(sizeof(FusedTile) / 4)) put(reinterpret_cast<uint32_t*>(&ws.ftile[tile]) + tid, 0u);      // (a kernel boundary lies between this and the fused launch)
+    if (g.fused && tile == 0 && tid >= 32 && tid < 32 + kXcds) put(&ws.fsched->queue[tid - 32].ticket, 0u);
     if (tid == 0) {
         put(&st.fell_back, 0u);
         put(&st.spec, 0u);
@@ -266,7 +306,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
     const float a1_min = fminf(sh.frame[3], fminf(sh.frame[4], sh.frame[5]));
     const float a0_max = fmaxf(fabsf(sh.frame[0]), fmaxf(fabsf(sh.frame[1]), fabsf(sh.frame[2])));
     const float an_max = fmaxf(fabsf(sh.frame[6]), fmaxf(fabsf(sh.frame[7]), fabsf(sh.frame[8])));
-    if (m_kept < 3 || g.pixels < 16 || !(a1_min > 0.06f * a0_max + 2.0f * kSpecKw * an_max + 0.01f)) {
+    if (m_kept < 3 || g.pixels < 16 || !(a1_min > 0.06f * a0_max + 2.0f * g.spec_kw * an_max + 0.01f)) {
         give_up();
         return;
     }
@@ -342,7 +382,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         const float n_eff = fmaxf((float)mv * (spec_eff(g) / 4.0f), 4.0f);      // four histogram pixels per sector
         const float sd = sqrtf(f * (1.0f - f) / n_eff);
         const bool upper = (wave & 1) != 0;
-        const float level = upper ? f + kSpecSigmas * sd : f - kSpecSigmas * sd;
+        const float level = upper ? f + g.spec_sigmas * sd : f - g.spec_sigmas * sd;
         const bool open = mv < 16 || (upper ? level >= 1.0f : level <= 0.0f);
         const float pos = fminf(fmaxf(level, 0.0f), 1.0f) * (float)max(mv - 1, 0);
         const uint32_t rank = (uint32_t)min(max((int)(upper ? ceilf(pos) : floorf(pos)), 0), max(mv - 1, 0));
@@ -429,7 +469,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
     SX_STAMP(st, 6);
     if (wave < 4) {
         const float n_eff = fmaxf((float)ms * (spec_eff(g) / 4.0f), 4.0f);
-        const float level = 0.99f - kSpecSigmas * sqrtf(0.99f * 0.01f / n_eff);
+        const float level = 0.99f - g.spec_sigmas * sqrtf(0.99f * 0.01f / n_eff);
         const uint32_t rank = (uint32_t)max((int)floorf(fmaxf(level, 0.0f) * (float)max(ms - 1, 0)), 0);
         const uint32_t b = prior_pick_bin(sh.hist[wave], rank);
         if (lane == 0) sh.cthr[wave] = (level > 0.0f && b > 0) ? (float)b * (r_max / (float)kPriorBins) : -__builtin_huge_valf();      // the bin's lower edge
@@ -470,7 +510,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
             put(&pr->a1[i], sh.frame[3 + i]);
             put(&pr->an[i], sh.frame[6 + i]);
         }
-        put(&pr->kw, kSpecKw);
+        put(&pr->kw, g.spec_kw);
         put(&pr->kx, kSpecKx);
 #pragma unroll
         for (int q = 0; q < 4; ++q) put(&pr->cmax[q], __uint_as_float(sh.cmax[q]));
@@ -532,8 +572,52 @@ __device__ __forceinline__ void write_records(const uint32_t (*__restrict__ queu
     }
 }
 
-template <typename T, int V, int TPB, bool kInter>
-__device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, PassAScratch<TPB>* sh, const LevelTables<T>& tb) {
+// The fused transform's form of the same move: the tile's candidates of a slot are ONE dense array of 16-byte records
+// (od0, od1, od2, -), room reserved with one returning atomic per slot and flush -- the four of a flush issued together by
+// four lanes, so a flush waits one memory round trip, normally once per work item and wave (a wave queues ~300 of its 4096
+// pixels) -- and written with 16-byte write-through stores: the stage job of the same launch reads them from another CU.
+// Records beyond the array's capacity are dropped; the count says so and the slot takes the slow exact path.
+__device__ __forceinline__ void write_records_fused(const uint32_t (*__restrict__ queue)[kQueue2], uint32_t n, uint4* __restrict__ rec_tile, uint32_t cap, uint32_t* __restrict__ ncand) {
+    if (n == 0) return;
+    const uint32_t lane = lane_id();
+    uint32_t count[kSlots] = {0u, 0u, 0u, 0u};
+    for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
+        const uint32_t i = i0 + lane, flags = i < n ? queue[3][i] : 0u;
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) count[s] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(((flags >> s) & 1u) != 0));
+    }
+    uint32_t base = 0;
+    {
+        const uint32_t mine = lane == 0 ? count[0] : (lane == 1 ? count[1] : (lane == 2 ? count[2] : count[3]));
+        if (lane < (uint32_t)kSlots && mine) base = __hip_atomic_fetch_add(&ncand[lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t at0[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) at0[s] = (uint32_t)__builtin_amdgcn_readlane((int)base, s);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rec_tile, 0, (int)(kSlots * cap * 16u), 0x00020000);      // (rec_tile is wave-uniform; stores beyond the tile's records are dropped by the range check)
+    for (uint32_t i0 = 0; i0 < n; i0 += kWave) {
+        const uint32_t i = i0 + lane;
+        sx_u4 rec = {0u, 0u, 0u, 0u};
+        uint32_t flags = 0;
+        if (i < n) {
+            rec[0] = queue[0][i];
+            rec[1] = queue[1][i];
+            rec[2] = queue[2][i];
+            flags = queue[3][i];
+        }
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const bool has = ((flags >> s) & 1u) != 0;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(has);
+            const uint32_t at = at0[s] + rank_in_mask(mask);
+            if (has && at < cap) __builtin_amdgcn_raw_buffer_store_b128(rec, rsrc, (int)(((uint32_t)s * cap + at) * 16u), 0, 16);      // aux 16: sc1 (write-through)
+            at0[s] += (uint32_t)__popcll(mask);
+        }
+    }
+}
+
+template <typename T, int V, int TPB, bool kInter, bool kFused = false>
+__device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, PassAScratch<TPB>* sh, const LevelTables<T>& tb) {
     const int64_t p_begin = (int64_t)chunk_id * g.chunk;
     const int64_t p_end = min(p_begin + (int64_t)g.chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
@@ -572,7 +656,10 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
     float* cand_tile = ws.cand_od + (size_t)tile * kSlots * 3 * g.cap2;
     const uint32_t seg = (uint32_t)chunk_id * (TPB / kWave) + (uint32_t)wave, seg_base = seg * g.seg_cap;
     auto flush = [&]() {
-        write_records(queue, n_q, have, cand_tile, g, seg_base, st.over_count);
+        if constexpr (kFused)
+            write_records_fused(queue, n_q, ws.cand_rec + (size_t)tile * kSlots * g.fused_cap, g.fused_cap, ws.ftile[tile].ncand);
+        else
+            write_records(queue, n_q, have, cand_tile, g, seg_base, st.over_count);
         n_q = 0;
     };
 
@@ -702,9 +789,11 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
     if (speculate) {
         flush();
         if (lane_id() == 0) {
-            uint32_t* counts = ws.seg_count + ((size_t)tile * kSlots) * g.n_seg + seg;
+            if constexpr (!kFused) {
+                uint32_t* counts = ws.seg_count + ((size_t)tile * kSlots) * g.n_seg + seg;
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) put(&counts[(size_t)s * g.n_seg], have[s]);
+                for (int s = 0; s < kSlots; ++s) put(&counts[(size_t)s * g.n_seg], have[s]);
+            }
             if (below_a) atomicAdd(&sh->below[0], below_a);
             if (below_b) atomicAdd(&sh->below[1], below_b);
         }
@@ -714,7 +803,7 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < TPB / kWave; ++w) s += ss->red[w][threadIdx.x];
-        put(&ws.partial[item * kPartial + threadIdx.x], s);
+        if constexpr (kFused) st_agent(&ws.partial[item * kPartial + threadIdx.x], s); else put(&ws.partial[item * kPartial + threadIdx.x], s);
     }
     if (speculate && threadIdx.x == kPartial) {      // (no value comes back: nothing waits for these)
         if (sh->below[0]) atomicAdd(&st.below[0], sh->below[0]);
@@ -724,7 +813,16 @@ __device__ void pass_a_item(const T* __restrict__ images, const Geometry& g, con
 #pragma unroll
     for (int w = 0; w < TPB / kWave; ++w) kept_total += ss->red[w][0];      // workgroup-uniform
     // (see stats_item: a work item without kept pixels also leaves the moments of ALL its pixels)
-    if (__builtin_expect(kept_total < 3.0, 0)) stats_item_all_pixels<T, V, TPB, kInter>(img, g.pixels, p_begin, p_end, ws.partial_all + item * kPartial, ss);
+    if (__builtin_expect(kept_total < 3.0, 0)) {
+        stats_item_all_pixels<T, V, TPB, kInter>(img, g.pixels, p_begin, p_end, ws.partial_all + item * kPartial, ss);
+        if constexpr (kFused) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (plain stores in there: written back before the flag below; rare path)
+    }
+    if constexpr (kFused) {
+        // publish: every wave has drained its write-through stores and atomics, then ONE lane counts the work item in
+        drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&ws.ftile[tile].a_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <typename T, int V, bool kInter = false>
@@ -1032,7 +1130,7 @@ __device__ void exact_plane(const Geometry& g, const Workspace& ws, int tile, Sl
 
 // The proof obligations of an angle slot that do not depend on the answer, and the key range its candidates can span
 // (one thread).  check[0..1]: keys of the mapped boundaries, check[2..3]: 1 if that side is open.
-__device__ inline bool phi_slot_check(const PriorRecord* pr, const float (&v)[6], int j, double (&check)[8]) {
+__device__ inline bool phi_slot_check(const PriorRecord* pr, const float (&v)[6], int j, double (&check)[8], float rot_limit) {
     // the prior frame against the exact plane: V = F M; in-plane part Rt (t = Rt th + nu w), tilt nu
     float m0[3], m1[3];
     const float v0[3] = {v[0], v[2], v[4]}, v1[3] = {v[1], v[3], v[5]};
@@ -1043,7 +1141,7 @@ __device__ inline bool phi_slot_check(const PriorRecord* pr, const float (&v)[6]
     const float nu = __builtin_amdgcn_sqrtf(nu0 * nu0 + nu1 * nu1);
     const float stretch = __builtin_amdgcn_sqrtf(r00 * r00 + r01 * r01 + r10 * r10 + r11 * r11);      // >= the largest singular value of Rt
     const float kw = get(&pr->kw), kx = get(&pr->kx);
-    bool good = det > 0.9f && stretch < 1.6f && r00 > 0.8f && r11 > 0.8f && fabsf(r01) + fabsf(r10) < 0.04f && kx >= 1.2e-3f;
+    bool good = det > 0.9f && stretch < 1.6f && r00 > 0.8f && r11 > 0.8f && fabsf(r01) + fabsf(r10) < rot_limit && kx >= 1.2e-3f;
     // every kept pixel's exact angle inside (0, pi): t1 = r10 th0 + r11 th1 + nu1 w with th1 >= min(a1) |od|_1, ... (prior_kernel)
     {
         const float a1_min = fminf(pr->a1[0], fminf(pr->a1[1], pr->a1[2]));
@@ -1156,7 +1254,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
                 if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
             });
             publish_range(&sh, mn, mx);
-            if (threadIdx.x == kGroupThreads - 1) sh.ok = phi_slot_check(pr, v, j, sh.check) ? 1 : 0;
+            if (threadIdx.x == kGroupThreads - 1) sh.ok = phi_slot_check(pr, v, j, sh.check, g.spec_rot) ? 1 : 0;
             __syncthreads();
             if (stamps) SX_STAMP(st, 10);
             ok = sh.ok != 0;

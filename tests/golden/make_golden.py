@@ -310,6 +310,85 @@ def g10_config5_tile_shape():
     print("g10 done")
 
 
+REAL_NAMES = ("target", "test_1", "test_2", "test_3", "test_4", "test_5")
+
+
+def real_images() -> torch.Tensor:
+    """The six 1024 x 1024 H&E tiles the reference ships for its own example (examples/data/*.png, used by
+    examples/torch_transform_example.py:43-64) as one uint8 (6, 3, 1024, 1024) tensor: target first."""
+    from PIL import Image
+
+    return torch.stack([torch.from_numpy(np.asarray(Image.open(f"/root/reference/examples/data/{n}.png").convert("RGB")).copy()).permute(2, 0, 1) for n in REAL_NAMES]).contiguous()
+
+
+def g11_real_tissue():
+    """Real tissue (missing #1): every other golden is an i.i.d. Beer-Lambert tile.  Inputs = the reference's own example
+    images (pixel arrays only; they also feed tools/sweep_real.py on the GPU box); outputs = the real reference on
+      * the 20 quadrants (512 x 512) of test_1..5, fit on the whole target image as the example does: per-tile intermediates and a
+        4096-pixel output subsample per tile for float32 and uint8 input, raw and normalize_to_0_1;
+      * six 224 x 224 crops (the example's RandomResizedCrop size): full outputs for f32 / u8 / bf16, Reinhard and histogram
+        matching on the same crops, StainNormalizerTransform in reference and batch mode (bf16, the module's defaults)."""
+    from tests.golden.cases import real_crops_224, real_quadrants_512
+
+    def thin(t: torch.Tensor) -> np.ndarray:
+        """float32 results: every 5th pixel of each plane (a fixture, not an archive); uint8 / bf16 results in full."""
+        return to_np(t.reshape(t.shape[0], 3, -1)[:, :, ::5].contiguous()) if t.dtype == torch.float32 else to_np(t)
+
+    imgs = real_images()
+    np.savez_compressed(HERE / "g11_real_images.npz", images_u8=to_np(imgs), names=np.array(REAL_NAMES))
+    target = imgs[0:1]
+    blob = {}
+    fit = stainx.Macenko(device="cpu", backend="torch").fit(target)
+    sm, tmc = fit._stain_matrix.clone(), fit._target_max_conc.clone()
+    blob["stain_matrix"], blob["target_max_conc"] = to_np(sm), to_np(tmc)
+    # ---- 512 x 512 quadrants
+    quads = torch.stack([imgs[i, :, y:y + 512, x:x + 512] for i, y, x in real_quadrants_512()]).contiguous()
+    stride = (512 * 512) // 4096
+    for name, dt in (("f32", torch.float32), ("u8", torch.uint8)):
+        x = synth.as_dtype(quads, dt)
+        m = stainx.Macenko(device="cpu", backend="torch")
+        m._stain_matrix, m._target_max_conc, m._is_fitted = sm, tmc, True
+        with Capture() as cap:
+            out = m.transform(x)
+        blob[f"q512_{name}_out_sub"] = to_np(out.reshape(len(quads), 3, -1)[:, :, ::stride].contiguous())
+        m.normalize_to_0_1 = True
+        blob[f"q512_{name}_out01_sub"] = to_np(m.transform(x).reshape(len(quads), 3, -1)[:, :, ::stride].contiguous())
+        for k, v in cap.stacked().items():
+            blob[f"q512_{name}_{k}"] = v
+    # ---- 224 x 224 crops: full outputs
+    crops = torch.stack([imgs[i, :, y:y + 224, x:x + 224] for i, y, x in real_crops_224()]).contiguous()
+    for name, dt in (("f32", torch.float32), ("u8", torch.uint8), ("bf16", torch.bfloat16)):
+        x = synth.as_dtype(crops, dt)
+        m = stainx.Macenko(device="cpu", backend="torch")
+        m._stain_matrix, m._target_max_conc, m._is_fitted = sm, tmc, True
+        with Capture() as cap:
+            blob[f"c224_{name}_out"] = thin(m.transform(x))
+        m.normalize_to_0_1 = True
+        blob[f"c224_{name}_out01"] = thin(m.transform(x))
+        if name == "f32":
+            for k, v in cap.stacked().items():
+                blob[f"c224_{k}"] = v
+    # the pooled fit over real tiles (compute_reference_stain_matrix_torch over the six crops)
+    pooled = stainx.Macenko(device="cpu", backend="torch").fit(crops)
+    blob["c224_pooled_he"], blob["c224_pooled_max_c"] = to_np(pooled._stain_matrix), to_np(pooled._target_max_conc)
+    # siblings on the same crops, fit on the target's top-left 512 x 512 quadrant
+    ref512 = imgs[0:1, :, :512, :512].contiguous()
+    r = stainx.Reinhard(device="cpu", backend="torch").fit(ref512)
+    blob["c224_reinhard_ref_mean"], blob["c224_reinhard_ref_std"] = to_np(r._reference_mean), to_np(r._reference_std)
+    blob["c224_reinhard_u8"] = to_np(r.transform(crops))
+    blob["c224_reinhard_f32"] = thin(r.transform(synth.as_dtype(crops, torch.float32)))
+    h = stainx.HistogramMatching(device="cpu", backend="torch").fit(ref512)
+    blob["c224_hm_u8"] = to_np(h.transform(crops))
+    blob["c224_hm_f32"] = thin(h.transform(synth.as_dtype(crops, torch.float32)))
+    # the module as the example builds it (reference = the whole target image, module defaults), and in batch mode
+    t = stainx.StainNormalizerTransform(method="macenko", mode="reference", reference=synth.as_dtype(target, torch.bfloat16), device="cpu", backend="torch")
+    blob["c224_module_reference_bf16"] = to_np(t(synth.as_dtype(crops, torch.bfloat16)))
+    tb = stainx.StainNormalizerTransform(method="macenko", mode="batch", device="cpu", backend="torch", batch_ref_index=2)
+    blob["c224_module_batch_f32"] = thin(tb(synth.as_dtype(crops, torch.float32)))
+    np.savez_compressed(HERE / "g11_real_tissue.npz", **blob)
+    print("g11 done")
+
+
 def g9_histogram_matching_random():
     """80 random small cases (uniform noise, odd sizes, four dtypes): the reference's float32 LUT arithmetic depends on
     the last bit of a `sum()` whose order is ATen's vectorised one -- these cases pin it (a restatement that adds the 256
@@ -327,9 +406,9 @@ def g9_histogram_matching_random():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11"]
     table = {"g1": g1_macenko_small, "g2": g2_macenko_config2, "g3": g3_macenko_fit, "g4": g4_reinhard,
              "g5": g5_histogram_matching, "g6": g6_edge_cases, "g8": g8_transform_module, "g9": g9_histogram_matching_random,
-             "g10": g10_config5_tile_shape}
+             "g10": g10_config5_tile_shape, "g11": g11_real_tissue}
     for w in which:
         table[w]()

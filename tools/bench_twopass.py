@@ -21,12 +21,14 @@ def timed(flags, steps=300, warm=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps * 1e3, out
 
-t2, o2 = timed(0)
+tf, of = timed(_native.MACENKO_TWO_PASS | _native.MACENKO_FUSE)         # the fused launch where it can run (opt-in)
+form = _native.require().sx_macenko_form(_native.DTYPE_CODES[dt], n, h, w, _native.MACENKO_TWO_PASS | _native.MACENKO_FUSE)
+t2, o2 = timed(_native.MACENKO_TWO_PASS)                                # the two-pass form as four launches
 p2 = be.tile_params(n)
 t1, o1 = timed(_native.MACENKO_CLASSIC)
-same = torch.equal(o1.view(torch.uint8), o2.view(torch.uint8))
+same = torch.equal(o1.view(torch.uint8), o2.view(torch.uint8)) and torch.equal(o1.view(torch.uint8), of.view(torch.uint8))
 px = n * h * w
-print(json.dumps({"shape": [n, 3, h, w], "dtype": str(dt), "two_pass_us": round(t2, 1), "four_pass_us": round(t1, 1), "bitwise_equal": same,
+print(json.dumps({"shape": [n, 3, h, w], "dtype": str(dt), "fused_form": form, "fused_us": round(tf, 1), "two_pass_us": round(t2, 1), "four_pass_us": round(t1, 1), "bitwise_equal": same,
                   "two_pass_MPs": round(px / t2, 0), "fell_back_tiles": int((p2["fell_back"] != 0).sum()),
                   "candidates_pct_per_slot": [round(float(v), 2) for v in (p2["n_candidates"].double().mean(0) / (h * w) * 100)],
                   "stamps_us_median(prior 0-7, phi 8-11, conc 12-15)": [round(float(v), 1) for v in p2["stamps_us"].median(0).values],
