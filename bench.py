@@ -2,7 +2,7 @@
 """Headline benchmark: megapixels/s of ``Macenko.transform`` on 64x3x512x512 fp32 tiles per GPU
 (BASELINE.json configs[1]), inputs resident in HBM, reference-mode (fit once, excluded from timing).
 
-    python bench.py --gpus N --steps K --warmup W [--workload transform|fit_transform_pooled]
+    python bench.py --gpus N --steps K --warmup W [--workload transform|fit_transform_pooled|hm_config3|module_config5|real_tiles]
 
 For N > 1 the driver launches it under ``torch.distributed.run`` (one rank per GPU, RCCL).  Tiles are
 independent units, so every rank transforms its own tiles with no data-path collective
@@ -22,6 +22,11 @@ One JSON line on stdout (rank 0).  Besides the contract fields it carries
                   only while the kernel sources still hash to what those passes ran (else null).
   cpu_baseline -- the CPU oracle (a numpy port of the reference's backend="torch" path) timed on this
                   box's host cores over a bounded sample of the same workload (rank 0, N=1 only).
+
+``--workload hm_config3`` (BASELINE configs[2]: HistogramMatching.transform, 64x3x1024x1024 uint8, 6 B/px), ``module_config5``
+(configs[4]: StainNormalizerTransform(macenko, reference), 256x3x224x224 bf16 per GPU, 12 B/px) and ``real_tiles`` (the headline
+transform on 64 crops of 512x512 from the reference's own example images, tests/golden/g11_real_images.npz, instead of synthetic
+tiles) print the same kind of line for the other single-GPU configurations; replicas / weak scaling as for ``transform``.
 
 ``--workload fit_transform_pooled`` (BASELINE configs[3]): every rank holds 64 tiles; one step = ONE stain estimate
 pooled over all ranks' tiles (small RCCL exchanges, ``stainx_amd.distributed``) + the transform of the local tiles to it;
@@ -58,7 +63,7 @@ def parse() -> argparse.Namespace:
     # multiplies ms_per_step several times, inside 1000 steps it adds half.
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", choices=("transform", "fit_transform_pooled"), default="transform")
+    ap.add_argument("--workload", choices=("transform", "fit_transform_pooled", "hm_config3", "module_config5", "real_tiles"), default="transform")
     ap.add_argument("--batches", type=int, default=2, help="different input batches the timed loop rotates over (1: one buffer)")
     ap.add_argument("--cpu-tiles", type=int, default=64, help="tiles of the workload the CPU baseline is timed on")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -124,6 +129,98 @@ def timed_loop(fn, steps: int, barrier):
     return elapsed, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)], out
 
 
+def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout) -> None:
+    """hm_config3 / module_config5 / real_tiles: the same protocol (warm-up, K timed steps over rotating batches, barrier +
+    synchronize on both sides, max over ranks), roofline on the workload's own algorithmic bytes, CPU oracle on a bounded sample."""
+    import numpy as np
+
+    from oracle import stain_oracle as so
+    from stainx_amd import HistogramMatching, Macenko, StainNormalizerTransform, synth
+
+    n_batches = max(1, args.batches)
+    if args.workload == "hm_config3":
+        n, h, w, bpp, dt_name = 64, 1024, 1024, 6, "u8"
+        ref = synth.noise_u8((1, 3, h, w), 42)
+        batches_cpu = [synth.noise_u8((n, 3, h, w), 43 + 7 * (rank + world * b)) for b in range(n_batches)]
+        norm = HistogramMatching(device=dev, backend="torch_hip").fit(ref.to(dev))
+        call = norm.transform
+        metric = "megapixels/sec HistogramMatching transform, 64x3x1024x1024 uint8"
+        workload = "HistogramMatching transform, 64x3x1024x1024 uint8 per GPU (BASELINE configs[2])"
+        kernel = "histogram (LDS sub-histograms, integer counts) + LUT + apply: 3 R + 3 R + 3 W bytes per pixel moved for the 6 algorithmic"
+        cpu_fn = lambda sample: so.hm_transform(sample, so.hm_fit(ref.numpy()))
+        cpu_sample, exact = batches_cpu[0][:4].numpy(), True
+    elif args.workload == "module_config5":
+        n, h, w, bpp, dt_name = 256, 224, 224, 12, "bf16"
+        ref = synth.reference_tile(h, w)
+        batches_cpu = [synth.as_dtype(synth.he_batch(n, h, w, seed0=1000 + n * (rank + world * b)), torch.bfloat16) for b in range(n_batches)]
+        module = StainNormalizerTransform(method="macenko", mode="reference", reference=synth.as_dtype(ref, torch.bfloat16).to(dev), device=dev, backend="torch_hip")
+        call = module
+        metric = "megapixels/sec StainNormalizerTransform(macenko, reference), 256x3x224x224 bf16"
+        workload = "StainNormalizerTransform(method=macenko, mode=reference) on 256x3x224x224 bf16 per GPU, data on the device (BASELINE configs[4]; one replica per GPU)"
+        kernel = "all launches of one sx_macenko_transform call on bf16 tiles (four-pass form: stats, plane, bracket<phi>, stain, bracket<conc>, scale, reconstruct with the fused /255)"
+        he, max_c = (t.float().cpu().numpy() for t in (module.normalizer._stain_matrix, module.normalizer._target_max_conc))
+        cpu_fn = lambda sample: so.macenko_transform(sample, he, max_c)
+        cpu_sample, exact = batches_cpu[0][:32].float().numpy(), False
+    else:
+        n, h, w, bpp, dt_name = 64, 512, 512, 24, "f32"
+        imgs = torch.from_numpy(np.load(str(ROOT / "tests" / "golden" / "g11_real_images.npz"))["images_u8"])
+        crops = torch.stack([imgs[i, :, y:y + h, x:x + w] for i in range(6) for y in range(0, 513, 128) for x in range(0, 513, 128)])      # 150 overlapping tiles
+        picks = [torch.arange(b, 150, 150 / n).long()[:n] for b in range(n_batches)]
+        batches_cpu = [synth.as_dtype(crops[(pk + rank) % 150], torch.float32) for pk in picks]
+        norm = Macenko(device=dev, backend="torch_hip").fit(imgs[0:1].to(dev))
+        call = norm.transform
+        metric = "megapixels/sec Macenko transform, 64x3x512x512 fp32, REAL tissue (crops of the reference's example images)"
+        workload = "Macenko reference-mode transform, 64x3x512x512 fp32 per GPU, crops of the reference's six example tiles (fit on its target image)"
+        kernel = "all launches of one sx_macenko_transform call (the form the backend's feedback settles on for this data)"
+        he, max_c = norm._stain_matrix.cpu().numpy(), norm._target_max_conc.cpu().numpy()
+        cpu_fn = lambda sample: so.macenko_transform(sample, he, max_c)
+        cpu_sample, exact = batches_cpu[0][:16].numpy(), False
+    batches = [b.to(dev) for b in batches_cpu]
+    pixels = n * h * w
+    for i in range(args.warmup):
+        out = call(batches[i % n_batches])
+    elapsed, step_ms, out = timed_loop(lambda i: call(batches[i % n_batches]), args.steps, barrier)
+    elapsed = max_over_ranks(elapsed)
+    if rank != 0:
+        return
+    dev_ms = sum(step_ms) / len(step_ms)
+    achieved = pixels * bpp / (dev_ms * 1e-3) / 1e9
+    line = {"metric": metric, "value": round(world * pixels / 1e6 / (elapsed / args.steps), 1), "unit": "megapixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt_name,
+            "data": "real (tests/golden/g11_real_images.npz)" if args.workload == "real_tiles" else "synthetic",
+            "config": {"workload": workload, "tiles_per_gpu": n, "height": h, "width": w, "input_batches_rotated": n_batches, "parallelism": f"replicas / tiles sharded over {world} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": pixels * bpp, "device_ms_per_call": round(dev_ms, 4), "device_ms_min": round(min(step_ms), 4), "kernel": kernel},
+            "kernel_source_hash": source_hash()}
+    if args.workload == "real_tiles":
+        engine = norm._get_backend_impl()
+        line["form"] = "four-pass (the two-pass form left its speculative path on some tiles; the backend's feedback switched)" if int(engine._classic_left) > 0 else "two-pass"
+    if world == 1 and not args.no_cpu:
+        from threadpoolctl import threadpool_limits
+
+        with threadpool_limits(limits=1):
+            want = cpu_fn(cpu_sample)
+            reps, t0 = 1, time.perf_counter()
+            while True:
+                cpu_fn(cpu_sample)
+                reps += 1
+                dt = time.perf_counter() - t0
+                if dt >= 10.0 or reps >= 32:
+                    break
+        k = cpu_sample.shape[0]
+        line["cpu_baseline"] = {"value": round((reps - 1) * k * h * w / 1e6 / dt, 3), "unit": "megapixels/s", "cores": 1, "kind": "port",
+                                "sample": f"{reps - 1} x the first {k} tiles of the workload, numpy oracle on one core, {dt:.1f} s; host has {os.cpu_count()} cores"}
+        # parity of a GPU result against the oracle on the same sample (HM pools its histogram over the batch it is given: the sample alone)
+        got = call(batches[0][:k].contiguous()).float().cpu()
+        w_t = torch.from_numpy(np.asarray(want)).float() / (255.0 if args.workload == "module_config5" else 1.0)
+        line["max_abs_vs_oracle"] = float((got - w_t).abs().max())
+        line["max_abs_vs_oracle_note"] = "grey levels, bit-exact expected" if exact else ("[0, 1] scale (module default normalize_to_0_1), bf16 storage" if args.workload == "module_config5" else "0-255 scale")
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(line), flush=True)
+    os.dup2(2, 1)
+
+
 def main() -> None:
     args = parse()
     # Only the result line may reach stdout: libraries underneath print there (RCCL's version banner at communicator
@@ -172,6 +269,13 @@ def main() -> None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    if args.workload in ("hm_config3", "module_config5", "real_tiles"):
+        other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # synthetic Beer-Lambert tiles: rank r, batch b uses seeds 1000 + 64 (r + world b) ...
     n_batches = max(1, args.batches)
     x_cpu = synth.as_dtype(synth.he_batch(TILES, HEIGHT, WIDTH, seed0=1000 + TILES * rank), torch.float32)
@@ -206,12 +310,12 @@ def main() -> None:
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"Macenko batch-mode fit_transform, {world * TILES}x3x512x512 fp32 sharded over {world} GPU(s) with RCCL statistics exchanges (BASELINE configs[3] is this at 8 GPUs)",
                            "tiles_per_gpu": TILES, "height": HEIGHT, "width": WIDTH, "input_batches_rotated": n_batches,
-                           "parallelism": f"tiles sharded over {world} GPU(s); pooled fit: 1 all-reduce of 10 fp64 moments, 1 all-gather of 48 KB samples, then per percentile stage 1 all-reduce of ~8 KB int64 counts + 2 all-gathers of <= 32 KB candidate keys; transform local"},
+                           "parallelism": f"tiles sharded over {world} GPU(s); pooled fit: 1 all-gather of (tile count, 10 fp64 moments, 48 KB sample) per rank, then per percentile stage 1 all-reduce of ~8 KB int64 counts + 1 all-gather of (2 counts, <= 32 KB candidate keys); transform local"},
                 "collective_ms": round(collective_ms, 4), "collectives_per_step": n_collectives, "backend": dist.get_backend(),
                 "roofline": {"bound": "hbm", "achieved": round(pixels * BYTES_PER_PIXEL / (dev_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(pixels * BYTES_PER_PIXEL / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                              "algorithmic_bytes_per_launch": pixels * BYTES_PER_PIXEL, "device_ms_per_call": round(dev_ms, 4),
-                             "kernel": "pooled fit (stats, bracket passes, pool kernels, per-group stages; host choreography with six small collectives) + transform of the local tiles"},
+                             "kernel": "pooled fit (stats, bracket passes, pool kernels, per-group stages; host choreography with five small collectives) + transform of the local tiles"},
             }
             sys.stdout.flush()
             os.dup2(real_stdout, 1)

@@ -70,8 +70,13 @@ def od_covariance(od_rows: np.ndarray) -> np.ndarray:
     n = od_rows.shape[0]
     if n <= 1:
         return np.zeros((3, 3), dtype=F32)
-    xt = od_rows.T.astype(F32)
-    centred = xt - xt.mean(axis=1, keepdims=True, dtype=F32)
+    # torch's float32 `mean` adds with a cascade of vector accumulators (error ~1e-7 relative whatever n); numpy's float32 sum over
+    # a strided axis is a plain running sum, which on the 16.7 M pixels of a pooled 64-tile fit loses two digits of the mean and
+    # turns the stain plane by several degrees (found by tests/test_distributed_gpu.py::test_config4_...: the real reference agrees
+    # with a float64 evaluation there, this restatement did not).  The float64-accumulated mean, rounded to float32, is torch's
+    # value to the last bit or two.
+    xt = np.ascontiguousarray(od_rows.T.astype(F32))
+    centred = xt - xt.mean(axis=1, keepdims=True, dtype=np.float64).astype(F32)
     return (centred @ centred.T) / F32(n - 1)
 
 

@@ -143,41 +143,70 @@ def macenko_fit_transform_pooled(local_images: torch.Tensor, *, group=None, step
                                  method: str = "brackets") -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """``fit_transform`` of a batch sharded across ranks (BASELINE configs[3]; reference: base.py:51-61 on the pooled estimate of
     torch_backend.py:463-519): ONE stain estimate over the union of every rank's tiles becomes the target, then every rank
-    transforms its own tiles to it -- the only exchanges are the fit's small statistics.  Returns ``(out, HE, maxC)``."""
+    transforms its own tiles to it -- the only exchanges are the fit's small statistics.  Returns ``(out, HE, maxC)``.
+
+    The bracket form's "did every bracket hold" word is read back asynchronously and looked at AFTER the transform has been
+    queued (the host never waits for the fit before it can launch the transform); in the rare case that it did not hold, the fit
+    is repeated with the radix rounds and the transform with it."""
     if steps is None:
         from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
         steps = MacenkoHIP(device if device is not None else local_images.device)
-    he, max_c = macenko_fit_pooled(local_images, group=group, steps=steps, method=method)
-    return steps.transform(local_images, he, max_c, normalize_to_0_1=normalize_to_0_1), he, max_c
+    he, max_c, pending = _macenko_fit_pooled(local_images, group, steps, method, defer_status=True)
+    out = steps.transform(local_images, he, max_c, normalize_to_0_1=normalize_to_0_1)
+    if pending is not None and not pending():
+        he, max_c, _ = _macenko_fit_pooled(local_images, group, steps, "radix", defer_status=False)
+        out = steps.transform(local_images, he, max_c, normalize_to_0_1=normalize_to_0_1)
+    return out, he, max_c
 
 
 def macenko_fit_pooled(local_images: torch.Tensor, *, group=None, steps: Any | None = None, device=None, method: str = "brackets") -> tuple[torch.Tensor, torch.Tensor]:
     """``(HE (3,2), maxC (2,))`` pooled over the union of every rank's ``local_images`` (N_r,3,H,W).
 
-    ``method="brackets"`` (default when the steps provider has the ``pfit_*`` steps): three passes over the local tiles,
-    one all-reduce of 10 moments, one all-gather of the ranks' pixel samples, and per percentile stage one all-reduce of
-    ~8 KB of integer counts plus one all-gather of <= 32 KB of candidate keys.  If a bracket does not hold (reported by
-    the last step) the fit is repeated with ``method="radix"``: nine passes, nine all-reduces, always exact."""
+    ``method="brackets"`` (default when the steps provider has the ``pfit_*`` steps): three passes over the local tiles and FIVE
+    small exchanges -- one all-gather of every rank's {tile count, 10 fp64 moments, 48 KB pixel sample}, then per percentile stage
+    one all-reduce of ~8 KB of integer counts and one all-gather of {2 counts, <= 32 KB of candidate keys}.  If a bracket does not
+    hold (reported by the last step) the fit is repeated with ``method="radix"``: nine passes, nine all-reduces, always exact."""
     if steps is None:
         from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
         steps = MacenkoHIP(device if device is not None else local_images.device)
+    he, max_c, _ = _macenko_fit_pooled(local_images, group, steps, method, defer_status=False)
+    return he, max_c
+
+
+def _macenko_fit_pooled(local_images, group, steps, method: str, defer_status: bool):
     if method not in ("brackets", "radix"):
         raise ValueError(f"method must be 'brackets' or 'radix', got {method!r}")
-    # (both methods: a rank without tiles must fail on EVERY rank here, not leave the others in the next collective)
-    tiles = tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
     if method == "brackets" and hasattr(steps, "pfit_stats"):
-        result = _macenko_fit_pooled_brackets(local_images, group, steps, tiles)
-        if result is not None:
-            return result
+        result = _macenko_fit_pooled_brackets(local_images, group, steps)      # (raises on EVERY rank if some rank holds no tile)
+        he, max_c, status = result
+        if defer_status and status.is_cuda:
+            host = torch.empty(1, dtype=torch.int32).pin_memory()
+            host.copy_(status, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+
+            def held() -> bool:
+                done.synchronize()      # (a four-byte copy queued BEFORE the transform: long done by the time the host gets here)
+                return int(host[0]) == 0
+
+            return he, max_c, held
+        # the same on every rank by construction (every rank ran the same selection on the same union), so the decision to
+        # repeat with the radix rounds is collective without another exchange
+        if int(status.item()) == 0:
+            return he, max_c, None
+    else:
+        # (both methods: a rank without tiles must fail on EVERY rank here, not leave the others in the next collective)
+        tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
     moments = all_reduce_sum(steps.dfit_moments(local_images), group)
     state = steps.dfit_begin(moments)
     for stage in (0, 1):                      # 0: angle percentiles, 1: concentration percentiles
         for _ in range(4):                    # byte-wise radix rounds
             hist = all_reduce_sum(steps.dfit_histogram(local_images, state, stage), group)
             steps.dfit_advance(state, stage, hist)
-    return steps.dfit_result(state)
+    he, max_c = steps.dfit_result(state)
+    return he, max_c, None
 
 
 def _exchange_device(steps, local_images: torch.Tensor):
@@ -186,37 +215,57 @@ def _exchange_device(steps, local_images: torch.Tensor):
     return steps.device if hasattr(steps, "device") else local_images.device
 
 
-def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, tiles: list[int]):
+def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _share: int | None = None):
+    """-> (HE, maxC, status): status is a one-element int32 tensor, non-zero if a bracket missed (the caller then repeats the fit
+    with the radix rounds)."""
     n, _, h, w = local_images.shape
     shape = (int(n), int(h), int(w))
-    size = len(tiles)                                 # (1 when the collectives are skipped)
-    n_all = int(sum(tiles)) * int(h) * int(w)
-    if n_all >= 1 << 32:
-        raise ValueError(f"a pooled fit over {n_all} pixels exceeds the 2^32 the native counters hold; fit on a subset of the tiles")
-    moments, sample = steps.pfit_stats(local_images)
-    moments = all_reduce_sum(moments, group)
-    if _skip_collective(world(group)[1], None):
-        union, sample_count = sample, steps.pfit_sample_count(int(n), int(h), int(w))
+    dev = _exchange_device(steps, local_images)
+    skip = _skip_collective(world(group)[1], None)
+    if int(n) <= 0 and skip:
+        raise ValueError(f"every rank needs at least one tile for a pooled statistic, got tiles per rank {[int(n)]}")
+    if int(n) > 0:
+        moments, sample = steps.pfit_stats(local_images)
+    else:      # a rank without tiles still has to take part in the exchange that tells every rank so
+        moments, sample = torch.zeros(10, dtype=torch.float64, device=dev), torch.zeros((3, 4096), dtype=torch.float32, device=dev)
+    if skip:
+        tiles, union, sample_count = [int(n)], sample, steps.pfit_sample_count(int(n), int(h), int(w))
     else:
-        samples = all_gather_stack(sample, group)                           # (world, 3, 4096)
-        pieces = [samples[r][:, : steps.pfit_sample_count(int(tiles[r]), int(h), int(w)) : size] for r in range(size)]
-        cat = torch.cat(pieces, dim=1)[:, :4096]
+        # ONE all-gather carries what used to be three exchanges: tile count, moments, pixel sample -- as bytes
+        mine = torch.cat([torch.full((1,), int(n), dtype=torch.int64, device=moments.device).view(torch.uint8), moments.contiguous().view(torch.uint8),
+                          sample.contiguous().view(torch.uint8).flatten()])
+        got = all_gather_stack(mine, group)                                                   # (world, 8 + 80 + 49152)
+        tiles = [int(v) for v in got[:, :8].contiguous().view(torch.int64).flatten().tolist()]      # the step's one early host read (only the first pass is queued)
+        if min(tiles) <= 0:
+            raise ValueError(f"every rank needs at least one tile for a pooled statistic, got tiles per rank {tiles} (shard with shard_bounds over >= world_size tiles)")
+        size = len(tiles)
+        moments = got[:, 8:88].contiguous().view(torch.float64).sum(dim=0)                   # the same sum on every rank
+        samples = got[:, 88:].contiguous().view(torch.float32).reshape(size, 3, 4096)
+        counts = [steps.pfit_sample_count(int(tiles[r]), int(h), int(w)) for r in range(size)]
+        if len(set(counts)) == 1:      # equal shards: every world-th column of every rank's sample, one strided copy
+            cat = samples[:, :, : counts[0] : size].permute(1, 0, 2).reshape(3, -1)[:, :4096]
+        else:
+            cat = torch.cat([samples[r][:, : counts[r] : size] for r in range(size)], dim=1)[:, :4096]
         sample_count = int(cat.shape[1])
         union = torch.zeros((3, 4096), dtype=torch.float32, device=cat.device)
         union[:, :sample_count] = cat
+    n_all = int(sum(tiles)) * int(h) * int(w)
+    if n_all >= 1 << 32:
+        raise ValueError(f"a pooled fit over {n_all} pixels exceeds the 2^32 the native counters hold; fit on a subset of the tiles")
+    size = len(tiles)
     steps.pfit_plane(moments, n_all, union, sample_count, shape)
-    share = 32768 // size          # every rank's part of the compact candidate list
+    share = int(_share) if _share else 32768 // size          # every rank's part of the compact candidate list (_share: tests mimic a larger world)
     out = None
     for stage in (0, 1):
         sums = all_reduce_sum(steps.pfit_pass(local_images, stage, n_all, sample_count), group)
         compact, counts = steps.pfit_gather(sums, stage, n_all, sample_count, shape, share)
-        out = steps.pfit_finish(all_gather_stack(compact, group), all_gather_stack(counts, group), stage, n_all, sample_count, shape)
-    he, max_c, status = out
-    # the same on every rank by construction (every rank ran the same selection on the same union), so the decision to
-    # repeat with the radix rounds is collective without another exchange; one host read of 4 bytes
-    if int(status.item()) != 0:
-        return None
-    return he, max_c
+        if skip:
+            g_compact, g_counts = compact.unsqueeze(0), counts.unsqueeze(0)
+        else:      # the two counts travel in front of the keys: one exchange
+            got = all_gather_stack(torch.cat([counts.to(torch.int32).flatten(), compact.to(torch.int32).flatten()]), group)
+            g_counts, g_compact = got[:, :2], got[:, 2:].reshape(size, 2, share)
+        out = steps.pfit_finish(g_compact, g_counts, stage, n_all, sample_count, shape)
+    return out
 
 
 def reinhard_transform_pooled(local_images: torch.Tensor, reference_mean, reference_std, *, group=None, steps: Any | None = None, device=None) -> torch.Tensor:

@@ -114,19 +114,23 @@ def _forced_worker(rank: int, world_size: int, port: int, out_dir: str):
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
         calls = {"n": 0}
-        real = dist.all_reduce
+        real, real_ag = dist.all_reduce, dist.all_gather
 
         def counting(*a, **k):
             calls["n"] += 1
             return real(*a, **k)
 
-        dist.all_reduce = counting
+        def counting_ag(*a, **k):
+            calls["n"] += 1
+            return real_ag(*a, **k)
+
+        dist.all_reduce, dist.all_gather = counting, counting_ag
         tiles = synth.he_batch(3, 48, 48, seed0=9)
         plain = sxd.macenko_fit_pooled(tiles, steps=NumpyMacenkoBracketSteps())
         assert calls["n"] == 0                                            # one rank: the collectives are skipped ...
         sxd.FORCE_COLLECTIVES = True
         forced = sxd.macenko_fit_pooled(tiles, steps=NumpyMacenkoBracketSteps())
-        assert calls["n"] >= 3                                            # ... unless forced (what the one-GPU RCCL test and bench mode use)
+        assert calls["n"] == 5                                            # ... unless forced (what the one-GPU RCCL test and bench mode use): five exchanges
         np.savez(os.path.join(out_dir, "forced.npz"), same=bool(torch.equal(plain[0], forced[0]) and torch.equal(plain[1], forced[1])))
     finally:
         sxd.FORCE_COLLECTIVES = None
