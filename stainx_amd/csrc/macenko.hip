@@ -113,6 +113,7 @@ struct Geometry {
     int spec_fail;                // diagnostic (SX_MACENKO_SPEC_FAIL): treat every speculation as failed -> the slow exact path
     float spec_kw, spec_eff_far, spec_eff_near, spec_rot, spec_sigmas;      // two-pass: the speculation's knobs (macenko_twopass.hpp: kSpecKw ...)
     int fused;                    // two-pass: pass A, the per-tile stages and the reconstruct pass in ONE launch (macenko_fused.hpp)
+    int dense;                    // two-pass: candidates in dense record arrays (tiles up to 512 x 512) instead of a segment per wave
     uint32_t fused_cap;           // fused: candidate records per tile and slot
     int fused_items;              // fused: pass-A work items of the call (= reconstruct work items)
 };
@@ -186,6 +187,7 @@ static size_t cand_words(int64_t n_tiles, int64_t pixels) {
 // detected and sends the slot to the slow path), and whether a tile size takes that form at all.
 constexpr int kLdsKeys = 16384;        // candidate keys of a slot the stages keep in LDS; the rest spill to the classic candidate area
 constexpr size_t kPriorRecordBytes = 384;
+static_assert(kLdsKeys >= 14336, "a dense candidate array (kFusedCapMax records) fits the stage's LDS key array");
 // per tile and slot: one segment per wave of pass A (an eighth of the wave's pixels, at least 128), and an overflow area of half
 // the segments' total behind them; cap2 is the stride of the three planes of a slot's arrays
 static int two_pass_segments(int64_t pixels) { return (int)((pixels + kChunk - 1) / kChunk) * (kStreamThreads / kWave); }
@@ -2540,8 +2542,13 @@ static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws,
         hipLaunchKernelGGL((prior_kernel<T, true, kInter>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
     else
         hipLaunchKernelGGL((prior_kernel<T, false, kInter>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
-    hipLaunchKernelGGL((pass_a_kernel<T, V, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
-    hipLaunchKernelGGL((estimate_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
+    if (g.dense) {
+        hipLaunchKernelGGL((pass_a_kernel<T, V, kInter, true>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+        hipLaunchKernelGGL((estimate_stage_kernel<T, true>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
+    } else {
+        hipLaunchKernelGGL((pass_a_kernel<T, V, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+        hipLaunchKernelGGL((estimate_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
+    }
     return check_launch("macenko two-pass estimate");
 }
 
@@ -2599,6 +2606,7 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
         g.two_pass = 0;
     }
     if (g.two_pass) {
+        g.dense = (fused_size(g.pixels) && !g.fused) ? 1 : 0;
         g.spec_kw = kSpecKw;
         g.spec_eff_far = kSpecEffFar;
         g.spec_eff_near = kSpecEffNear;
@@ -2879,7 +2887,10 @@ extern "C" int sx_macenko_takes_two_pass(int dtype, int64_t n, int64_t h, int64_
 extern "C" size_t sx_macenko_workspace_bytes_for(int dtype, int64_t n_tiles, int64_t height, int64_t width, unsigned flags) {
     if (n_tiles <= 0 || height <= 0 || width <= 0) return 0;
     const int form = sx_macenko_form(dtype, n_tiles, height, width, flags);
-    return macenko::workspace_bytes(n_tiles, height * width, form == 2 ? kWsFused : (form == 1 ? kWsTwoPass : kWsBase));
+    // (the four-launch two-pass form keeps its candidates in the dense record arrays too for tiles up to 512 x 512: only larger
+    // tiles need the per-wave segments)
+    const bool dense = form != 0 && fused_size(height * width);
+    return macenko::workspace_bytes(n_tiles, height * width, form == 0 ? kWsBase : (dense ? kWsFused : kWsTwoPass));
 }
 
 extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* sm, const float* tmc, unsigned flags, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {

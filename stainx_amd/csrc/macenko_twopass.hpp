@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         put(&st.over_count[tid], 0u);
     }
     if (tid < 2) put(&st.phi_pub[tid], 0ull);
-    if (g.fused && tid < (int)(sizeof(FusedTile) / 4)) put(reinterpret_cast<uint32_t*>(&ws.ftile[tile]) + tid, 0u);      // (a kernel boundary lies between this and the fused launch)
+    if ((g.fused || g.dense) && tid < (int)(sizeof(FusedTile) / 4)) put(reinterpret_cast<uint32_t*>(&ws.ftile[tile]) + tid, 0u);      // (a kernel boundary lies between this and the fused launch)
     if (g.fused && tile == 0 && tid >= 32 && tid < 32 + kXcds) put(&ws.fsched->queue[tid - 32].ticket, 0u);
     if (tid == 0) {
         put(&st.fell_back, 0u);
@@ -825,12 +825,16 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
     }
 }
 
-template <typename T, int V, bool kInter = false>
+// kDense: the candidates go to ONE dense array of 16-byte records per tile and slot, written through (the form the fused launch
+// uses, see write_records_fused) instead of a segment per wave: no dirty candidate lines for the kernel boundary to write back
+// (the gap between this launch and the stage was 4.7 us with 25 MB of them), one load per candidate in the stage instead of
+// three, and a third of the workspace.  Tiles up to 512 x 512; larger ones keep the segments.
+template <typename T, int V, bool kInter = false, bool kDense = false>
 __global__ __launch_bounds__(kStreamThreads) void pass_a_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ PassAScratch<kStreamThreads> sh;
     __shared__ LevelTables<T> tb;
     tb.fill();
-    pass_a_item<T, V, kStreamThreads, kInter>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh, tb);
+    pass_a_item<T, V, kStreamThreads, kInter, kDense>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh, tb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -845,6 +849,7 @@ struct alignas(16) SlotScratch {
     int ok, use_all;
     unsigned long long n_sel;
     uint32_t seg_prefix[kMaxSegments + 1], seg_total, seg_overflow, over_n;
+    uint32_t dense_n;                  // dense candidate arrays: candidates of the slot (clamped to the array's capacity)
     uint32_t own_key;
     int partner_ok;
     uint32_t k_floor, k_ceil, n_under;      // concentration slots: keys below k_floor are counted, not ranked; keys above k_ceil share the last bin
@@ -936,6 +941,52 @@ __device__ __forceinline__ void for_each_candidate(const CandPrefetch<kPre>& pf,
             const uint32_t o = off + u * team;
             if (o < cnt) fn(first + o, od[u]);
         }
+    }
+}
+
+// The same two steps over a DENSE candidate array (pass_a_kernel<kDense>): candidate i is record i; thread t takes i = t, t + blockDim, ...
+// -- adjacent lanes read adjacent records (one wave-instruction = 1 KB).  The first kPre records of a thread are requested before the
+// count is known (the range check of the buffer descriptor answers requests beyond the tile's records with zeros).
+template <int kPre>
+__device__ __forceinline__ void prefetch_candidates_dense(CandPrefetch<kPre>& pf, __amdgpu_buffer_rsrc_t rsrc) {
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const sx_u4 rec = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((threadIdx.x + (uint32_t)u * blockDim.x) * 16u), 0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pf.od[u][c] = __uint_as_float(rec[c]);
+    }
+}
+template <int kPre, class Fn>
+__device__ __forceinline__ void for_each_candidate_dense(const CandPrefetch<kPre>& pf, uint32_t n, __amdgpu_buffer_rsrc_t rsrc, Fn fn) {
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const uint32_t i = threadIdx.x + (uint32_t)u * blockDim.x;
+        if (i < n) fn(i, pf.od[u]);
+    }
+    constexpr int kFlight = 4;
+    for (uint32_t i0 = threadIdx.x + (uint32_t)kPre * blockDim.x; i0 < n; i0 += blockDim.x * kFlight) {
+        float od[kFlight][3];
+#pragma unroll
+        for (int u = 0; u < kFlight; ++u) {
+            const sx_u4 rec = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((i0 + (uint32_t)u * blockDim.x) * 16u), 0, 0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) od[u][c] = __uint_as_float(rec[c]);
+        }
+#pragma unroll
+        for (int u = 0; u < kFlight; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * blockDim.x;
+            if (i < n) fn(i, od[u]);
+        }
+    }
+}
+// the slot's count (one thread; a barrier before it is used): what segment_prefix() leaves for the segment form
+__device__ __forceinline__ void dense_count(SlotScratch* sh, const Geometry& g, const Workspace& ws, int tile, int slot) {
+    if (threadIdx.x == kWave - 1) {
+        const uint32_t n_raw = get(&ws.ftile[tile].ncand[slot]);
+        sh->seg_total = n_raw;
+        sh->dense_n = min(n_raw, g.fused_cap);
+        sh->over_n = 0;
+        sh->seg_overflow = n_raw > g.fused_cap ? 1u : 0u;
     }
 }
 
@@ -1212,7 +1263,7 @@ __device__ inline bool conc_slot_check(const PriorRecord* pr, const float (&pinv
 // before it started to wait.  As two launches the stages cost a kernel boundary plus ~3.5 us of launch ramp more, and the
 // second could not start its loads early.  The wait is bounded: a partner that does not show up (it would have to be
 // unscheduled while this workgroup spins -- the pair has adjacent block indices) is replaced by the slow exact select here.
-template <typename T>
+template <typename T, bool kDense = false>
 __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc) {
     __shared__ SlotScratch sh;
     const int tile = blockIdx.x >> 1, j = blockIdx.x & 1, slot = 2 + j;
@@ -1223,20 +1274,24 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     const bool stamps = j == 0;
     if (stamps) SX_STAMP(st, 8);
     const float* c0 = ws.cand_od + ((size_t)tile * kSlots + j) * 3 * g.cap2;
-    const size_t spill_words = g.cap2 > (uint32_t)kLdsKeys ? g.cap2 - kLdsKeys : 0u;
+    const size_t spill_words = (!kDense && g.cap2 > (uint32_t)kLdsKeys) ? g.cap2 - kLdsKeys : 0u;      // (a dense array holds at most kLdsKeys records: no spill)
+    // (tile and slot are workgroup-uniform; said so, the descriptors stay in scalar registers)
+    const uint4* rec_tile = ws.cand_rec + (size_t)__builtin_amdgcn_readfirstlane(tile) * kSlots * g.fused_cap;
+    const auto rsrc_phi = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(rec_tile + (size_t)__builtin_amdgcn_readfirstlane(j) * g.fused_cap), 0, (int)(g.fused_cap * 16u), 0x00020000);
+    const auto rsrc_conc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(rec_tile + (size_t)__builtin_amdgcn_readfirstlane(slot) * g.fused_cap), 0, (int)(g.fused_cap * 16u), 0x00020000);
     float v[6];
     bool use_all;
     unsigned long long rank_other;
     {   // ------------------------------------------------ angle percentile j
         CandPrefetch<8> pf;
-        prefetch_candidates(pf, g, c0);
+        if constexpr (kDense) prefetch_candidates_dense(pf, rsrc_phi); else prefetch_candidates(pf, g, c0);
         select_prepare(&sh);
-        segment_prefix(&sh, g, ws, tile, j);
+        if constexpr (kDense) dense_count(&sh, g, ws, tile, j); else segment_prefix(&sh, g, ws, tile, j);
         exact_plane<T>(g, ws, tile, &sh);
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = sh.vecs[i];
         if (stamps) SX_STAMP(st, 9);
-        const uint32_t n = sh.seg_prefix[g.n_seg] + sh.over_n, n_raw = sh.seg_total;
+        const uint32_t n = kDense ? sh.dense_n : sh.seg_prefix[g.n_seg] + sh.over_n, n_raw = sh.seg_total;
         use_all = sh.use_all != 0;
         const unsigned long long n_sel = sh.n_sel;
         const unsigned long long rank = nearest_rank_index(j ? 99.0 : 1.0, n_sel);      // alpha = 1 (torch_backend.py:421-422)
@@ -1247,12 +1302,13 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
         if (ok) {      // uniform
             // the exact keys of the candidates and their range; one thread works out the proof obligations meanwhile
             uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-            for_each_candidate(pf, &sh, g, c0, [&](uint32_t i, const float (&od)[3]) {
+            auto phi_key_of = [&](uint32_t i, const float (&od)[3]) {
                 const uint32_t k = angle_key(od, v);
                 mn = min(mn, k);
                 mx = max(mx, k);
                 if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
-            });
+            };
+            if constexpr (kDense) for_each_candidate_dense(pf, n, rsrc_phi, phi_key_of); else for_each_candidate(pf, &sh, g, c0, phi_key_of);
             publish_range(&sh, mn, mx);
             if (threadIdx.x == kGroupThreads - 1) sh.ok = phi_slot_check(pr, v, j, sh.check, g.spec_rot) ? 1 : 0;
             __syncthreads();
@@ -1293,10 +1349,10 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     if (stamps) SX_STAMP(st, 12);
     const float* c1 = ws.cand_od + ((size_t)tile * kSlots + slot) * 3 * g.cap2;
     CandPrefetch<12> pf;
-    prefetch_candidates(pf, g, c1);      // in flight while the partner finishes
+    if constexpr (kDense) prefetch_candidates_dense(pf, rsrc_conc); else prefetch_candidates(pf, g, c1);      // in flight while the partner finishes
     __syncthreads();                     // everyone is done with the first selection's scratch
     select_prepare(&sh);
-    segment_prefix(&sh, g, ws, tile, slot);      // (wave 0)
+    if constexpr (kDense) dense_count(&sh, g, ws, tile, slot); else segment_prefix(&sh, g, ws, tile, slot);      // (wave 0)
     auto vectors_and_check = [&](uint32_t partner_key) {      // one thread
         float he[6], pinv[6];
         const uint32_t key0 = j == 0 ? sh.own_key : partner_key, key1 = j == 0 ? partner_key : sh.own_key;
@@ -1343,7 +1399,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     for (int i = 0; i < 6; ++i) pinv[i] = sh.pinv[i];
     const unsigned long long n_all = (unsigned long long)g.pixels;
     const unsigned long long k99 = nearest_rank_index(99.0, n_all);          // torch_backend.py:447-448
-    const uint32_t n = sh.seg_prefix[g.n_seg] + sh.over_n, n_raw = sh.seg_total;
+    const uint32_t n = kDense ? sh.dense_n : sh.seg_prefix[g.n_seg] + sh.over_n, n_raw = sh.seg_total;
     if (stamps) SX_STAMP(st, 13);
     // every pixel that is not a candidate lies below the answer (that is what gets proved): the answer's rank among the candidates
     const unsigned long long outside = n_all - (unsigned long long)n;
@@ -1355,7 +1411,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     if (ok) {
         const uint32_t k_floor = sh.k_floor, k_ceil = sh.k_ceil;
         uint32_t mn = 0xFFFFFFFFu, mx = 0u, under = 0u;
-        for_each_candidate(pf, &sh, g, c1, [&](uint32_t i, const float (&od)[3]) {
+        auto conc_key_of = [&](uint32_t i, const float (&od)[3]) {
             float ca, cb;
             concentration(od, pinv, ca, cb);
             const uint32_t k = float_key(j ? cb : ca);
@@ -1363,7 +1419,8 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
             mx = max(mx, k);
             under += k < k_floor ? 1u : 0u;
             if (i < (uint32_t)kLdsKeys) sh.keys[i] = k; else put(&spill[i - kLdsKeys], k);
-        });
+        };
+        if constexpr (kDense) for_each_candidate_dense(pf, n, rsrc_conc, conc_key_of); else for_each_candidate(pf, &sh, g, c1, conc_key_of);
         publish_range(&sh, mn, mx);
         under = wave_total_u32(under);
         if (lane_id() == 0 && under) atomicAdd(&sh.n_under, under);
