@@ -948,18 +948,72 @@ __device__ __forceinline__ void reset_scratch(TileScratch* sh) {
 
 // Exact rank-th smallest (0-based) of the valid keys produced by key_at(i), i in [0,count): four 8-bit radix
 // rounds, keys recomputed/re-read in every round.  Slow path, whole workgroup.
-template <class KeyAt, class Scratch>
-__device__ uint32_t radix_select_stream(unsigned long long count, unsigned long long rank, KeyAt key_at, Scratch* sh) {
+// `keep` (optional, `count` words of global scratch this workgroup owns for the duration): the first round leaves every key there
+// (an invalid entry: 0xFFFFFFFF, which no finite value's key is) and the other three read them back -- one load instead of
+// recomputing a key from its pixel (three logarithms and ~60 instructions): the whole-tile select of a slot the two-pass form
+// could not speculate on takes ~0.13 ms instead of ~0.4 ms.
+// kThrough: the scratch is written THROUGH and read past the caches (agent-scope accesses).  Needed where the words are rewritten
+// by another workgroup later in the SAME launch (the fused transform parks the keys in the tile's output, which the tile's
+// reconstruct items then write from other XCDs: a plain store would leave a dirty line in this XCD's L2 whose write-back,
+// whenever it came, would land on top of the result).
+template <bool kThrough = false, class KeyAt, class Scratch>
+__device__ uint32_t radix_select_stream(unsigned long long count, unsigned long long rank, KeyAt key_at, Scratch* sh, uint32_t* __restrict__ keep = nullptr) {
     uint32_t prefix = 0, mask = 0;
     __syncthreads();
     if (threadIdx.x == 0) sh->radix_rank = rank;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int t = threadIdx.x; t < 256; t += blockDim.x) sh->radix_hist[t] = 0;
         __syncthreads();
-        for (unsigned long long i = threadIdx.x; i < count; i += blockDim.x) {
-            uint32_t k;
-            if (key_at(i, k) && ((k ^ prefix) & mask) == 0) atomicAdd(&sh->radix_hist[(k >> shift) & 255u], 1u);
+        // (a thread's consecutive keys mostly share their leading bytes -- one tile, one narrow range of angles or concentrations --,
+        // and 64 lanes adding to one LDS word take their turns: a thread counts a run of equal digits itself and adds once per run)
+        uint32_t last = 0xFFFFFFFFu, run = 0;
+        auto count_digit = [&](uint32_t k) {
+            const uint32_t d = (k >> shift) & 255u;
+            if (d == last) {
+                ++run;
+            } else {
+                if (run) atomicAdd(&sh->radix_hist[last], run);
+                last = d;
+                run = 1;
+            }
+        };
+        // (four keys per trip: their loads -- of the parked keys, or of the pixels a key is made from -- go out together; one key per
+        // trip made every round a chain of `count / blockDim` dependent memory round trips, 0.2 ms per round for a 512 x 512 tile)
+        constexpr int kTrip = 4;
+        const unsigned long long step = (unsigned long long)blockDim.x * kTrip;
+        if (keep != nullptr && shift < 24) {
+            for (unsigned long long i0 = threadIdx.x; i0 < count; i0 += step) {      // (written by this very thread in the first round: no fence needed)
+                uint32_t k[kTrip];
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u) {
+                    const unsigned long long i = i0 + (unsigned long long)u * blockDim.x;
+                    k[u] = i < count ? (kThrough ? __hip_atomic_load(&keep[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : keep[i]) : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u)
+                    if (k[u] != 0xFFFFFFFFu && ((k[u] ^ prefix) & mask) == 0) count_digit(k[u]);
+            }
+        } else {
+            for (unsigned long long i0 = threadIdx.x; i0 < count; i0 += step) {
+                uint32_t k[kTrip];
+                bool valid[kTrip];
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u) {
+                    const unsigned long long i = i0 + (unsigned long long)u * blockDim.x;
+                    k[u] = 0;
+                    valid[u] = i < count && key_at(i, k[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u) {
+                    const unsigned long long i = i0 + (unsigned long long)u * blockDim.x;
+                    if (keep != nullptr && i < count) {
+                        if constexpr (kThrough) __hip_atomic_store(&keep[i], valid[u] ? k[u] : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else keep[i] = valid[u] ? k[u] : 0xFFFFFFFFu;
+                    }
+                    if (valid[u] && ((k[u] ^ prefix) & mask) == 0) count_digit(k[u]);
+                }
+            }
         }
+        if (run) atomicAdd(&sh->radix_hist[last], run);
         __syncthreads();
         if (threadIdx.x < kWave) {
             uint32_t d;
@@ -1810,11 +1864,11 @@ __device__ void plane_stage(const T* __restrict__ images, const Geometry& g, con
 // ------------------------------------------------------------------------------------------------
 // exact order statistics of the two slots of a stage from what the streaming stage left behind
 // ------------------------------------------------------------------------------------------------
-template <typename T, class Scratch>
+template <typename T, bool kThrough = false, class Scratch>
 __device__ uint32_t select_whole_group(const T* __restrict__ images, const Geometry& g, int group, int slot, unsigned long long rank, const float* coef, bool use_all,
-                                       Scratch* sh) {
+                                       Scratch* sh, uint32_t* __restrict__ keep = nullptr) {
     const GroupPixels gp = group_pixels(g, group);
-    return radix_select_stream((unsigned long long)gp.count, rank,
+    return radix_select_stream<kThrough>((unsigned long long)gp.count, rank,
                                [&](unsigned long long i, uint32_t& k) {
                                    int64_t tile, p;
                                    gp.locate((int64_t)i, tile, p);
@@ -1830,7 +1884,7 @@ __device__ uint32_t select_whole_group(const T* __restrict__ images, const Geome
                                    }
                                    return true;
                                },
-                               sh);
+                               sh, keep);
 }
 
 // What resolve_pair() needs from memory, fetched at the top of the kernel in one batch (one memory latency for
@@ -2535,7 +2589,7 @@ static int run_estimate(const T* images, const Geometry& g, const Workspace& ws,
 
 // The estimate of the two-pass transform (macenko_twopass.hpp): prior, ONE pass over the input, two small stages.
 template <typename T, int V, bool kInter = false>
-static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws, const float* tmc, hipStream_t stream) {
+static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws, const float* tmc, hipStream_t stream, void* key_scratch = nullptr) {
     const unsigned n = (unsigned)g.n_tiles, grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     const bool quads = (g.pixels % 4 == 0) && aligned_for(images, 4 * sizeof(T));
     if (quads)
@@ -2544,10 +2598,10 @@ static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws,
         hipLaunchKernelGGL((prior_kernel<T, false, kInter>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
     if (g.dense) {
         hipLaunchKernelGGL((pass_a_kernel<T, V, kInter, true>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
-        hipLaunchKernelGGL((estimate_stage_kernel<T, true>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
+        hipLaunchKernelGGL((estimate_stage_kernel<T, true>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc, static_cast<uint32_t*>(key_scratch));
     } else {
         hipLaunchKernelGGL((pass_a_kernel<T, V, kInter>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
-        hipLaunchKernelGGL((estimate_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
+        hipLaunchKernelGGL((estimate_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc, static_cast<uint32_t*>(key_scratch));
     }
     return check_launch("macenko two-pass estimate");
 }
@@ -2573,7 +2627,9 @@ static int run_transform(const T* images, O* out, const Geometry& g, const Works
         hipLaunchKernelGGL((fast_kernel<T>), dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, images, g, ws, tmc);
         rc = check_launch("macenko fast estimate");
     } else if (g.two_pass) {
-        rc = run_two_pass<T, V, kInter>(images, g, ws, tmc, stream);
+        // (the output tile doubles as scratch for the keys of a slot that takes the slow exact path: nothing has been written there
+        // yet, the reconstruct launch overwrites it -- needs a plane of 4-byte elements per slot pair)
+        rc = run_two_pass<T, V, kInter>(images, g, ws, tmc, stream, sizeof(O) >= 4 ? static_cast<void*>(out) : nullptr);
     } else {
         rc = run_estimate<T, V, kInter>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
     }

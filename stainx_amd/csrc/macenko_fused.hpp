@@ -306,7 +306,8 @@ __device__ __forceinline__ void fused_exact_plane(const Geometry& g, const Works
 
 // Stage job (tile, j): estimate_stage_kernel's work for one of a tile's two slot pairs, on 256 threads.
 template <typename T>
-__device__ __forceinline__ void fused_stage_job(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int tile, int j, const float* __restrict__ target_max_conc, FusedStageScratch* sh, uint32_t unit) {
+__device__ __forceinline__ void fused_stage_job(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int tile, int j, const float* __restrict__ target_max_conc, FusedStageScratch* sh, uint32_t unit,
+                                                uint32_t* __restrict__ keep) {
     const int slot = 2 + j;
     GroupState& st = ws.state[tile];
     const PriorRecord* pr = &ws.prior[tile];
@@ -378,7 +379,7 @@ __device__ __forceinline__ void fused_stage_job(const T* __restrict__ images, co
                 atomicOr(&st.spec, (overflow ? 4u : why) << (8 + 4 * j));
                 atomicAdd(&ws.state[0].slow_slots, 1u);
             }
-            answer = select_whole_group<T>(images, g, tile, j, rank, v, use_all, sh);
+            answer = select_whole_group<T, true>(images, g, tile, j, rank, v, use_all, sh, keep);
         }
         if (threadIdx.x == 0) {
             put(&st.phi_key[j], answer);
@@ -426,7 +427,7 @@ __device__ __forceinline__ void fused_stage_job(const T* __restrict__ images, co
     }
     __syncthreads();
     if (__builtin_expect(sh->partner_ok == 0, 0)) {      // uniform; the partner never showed up: its percentile, the slow way
-        const uint32_t partner_key = select_whole_group<T>(images, g, tile, 1 - j, rank_other, v, use_all, sh);
+        const uint32_t partner_key = select_whole_group<T, true>(images, g, tile, 1 - j, rank_other, v, use_all, sh, keep);
         __syncthreads();
         fused_select_prepare(sh);
         if (threadIdx.x == kWave) vectors_and_check(partner_key);
@@ -478,7 +479,7 @@ __device__ __forceinline__ void fused_stage_job(const T* __restrict__ images, co
             atomicOr(&st.spec, (overflow ? 4u : why) << (8 + 4 * slot));
             atomicAdd(&ws.state[0].slow_slots, 1u);
         }
-        answer = select_whole_group<T>(images, g, tile, slot, k99, pinv, true, sh);
+        answer = select_whole_group<T, true>(images, g, tile, slot, k99, pinv, true, sh, keep);
     }
     if (threadIdx.x == 0) {
         const float mc = key_float(answer);
@@ -560,7 +561,9 @@ __global__ __launch_bounds__(kStreamThreads, 4) void fused_kernel(const T* __res
     } else if (ticket < n_items + n_jobs) {
         const uint32_t k = ticket - n_items, tile = (k >> 1) * (uint32_t)kXcds + queue;
         __builtin_amdgcn_s_setprio(3);      // a chain of short dependent phases: it must not queue behind streaming waves
-        fused_stage_job<T>(images, g, ws, (int)tile, (int)(k & 1u), target_max_conc, &sh.stage, blockIdx.x);
+        // (plane j of the tile's output, not written before the tile's reconstruct items run: key scratch of the slow exact path)
+        uint32_t* keep = sizeof(O) >= 4 ? reinterpret_cast<uint32_t*>(out + ((size_t)tile * 3 + (k & 1u)) * (size_t)g.pixels) : nullptr;
+        fused_stage_job<T>(images, g, ws, (int)tile, (int)(k & 1u), target_max_conc, &sh.stage, blockIdx.x, keep);
         SX_UNIT_STAMP(ws, blockIdx.x, 2);
     } else {
         const uint32_t k = ticket - n_items - n_jobs, tile = (k / bpt) * (uint32_t)kXcds + queue;

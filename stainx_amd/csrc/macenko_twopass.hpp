@@ -52,8 +52,16 @@ constexpr float kSpecSigmas = 5.0f;                   // half-width of a bracket
 // (the values travel in Geometry::spec_*: set by the host from the constants below -- diagnostic builds read overrides from the environment)
 constexpr float kSpecEffFar = 2.0f, kSpecEffNear = 1.0f;
 __device__ __forceinline__ float spec_eff(const Geometry& g) { return g.prior_step_q16 >= (8u << 16) ? g.spec_eff_far : g.spec_eff_near; }
-constexpr float kSpecKw = 0.05f, kSpecKx = 1.3e-3f;   // margin m = kw |w| + kx |od|_1 + 1e-6 (kx: the fp16 rounding of the pixel, 2^-10, with room)
-constexpr float kSpecRot = 0.04f;                     // largest in-plane rotation |r01| + |r10| between the prior frame and the exact plane a proof accepts
+// margin m = kw |w| + kx |od|_1 + 1e-6 (kx: the fp16 rounding of the pixel, 2^-10, with room).  kw buys tolerance to the TILT of the
+// prior plane against the exact one (a proof holds up to a tilt of about kw / 1.5): 0.05 was sized on the synthetic tiles, whose
+// covariance has lambda_mid / lambda_min ~ 260; the reference's real example tiles have 2 ... 15, the plane of a 6 % presample
+// tilts by 0.01 ... 0.03 and a third of the tiles lost their angle slots to it (profiles/r03_real_tiles_speculation_knobs.jsonl:
+// 31 slow slots in 64 tiles at 0.05, 14 at 0.1 with the rotation bound below; the synthetic batch pays 0.5 us for it).
+constexpr float kSpecKw = 0.10f, kSpecKx = 1.3e-3f;
+// largest in-plane rotation |r01| + |r10| between the prior frame and the exact plane a proof accepts.  The proofs map the tested
+// boundaries through the exact 2x2 (phi_slot_check: D = Rt d), so nothing in them needs the rotation to be small; 0.04 was a
+// sanity bound that real tiles (0.01 ... 0.03 from the presample alone) ran into.  r00, r11 > 0.8 still bound it to ~0.6 rad.
+constexpr float kSpecRot = 0.30f;
 constexpr uint32_t kSpecSlow = 1u, kSpecHazard = 2u;  // GroupState::spec bits
 constexpr int kMaxSegments = 256;                      // waves of pass A per tile (two_pass_size() keeps tiles within 64 work items)
 
@@ -1264,9 +1272,12 @@ __device__ inline bool conc_slot_check(const PriorRecord* pr, const float (&pinv
 // second could not start its loads early.  The wait is bounded: a partner that does not show up (it would have to be
 // unscheduled while this workgroup spins -- the pair has adjacent block indices) is replaced by the slow exact select here.
 template <typename T, bool kDense = false>
-__global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc) {
+__global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* __restrict__ images, Geometry g, Workspace ws, const float* __restrict__ target_max_conc,
+                                                                       uint32_t* __restrict__ key_scratch) {
     __shared__ SlotScratch sh;
     const int tile = blockIdx.x >> 1, j = blockIdx.x & 1, slot = 2 + j;
+    // the slow exact path's key scratch: plane j of the tile's (not yet written) output, one word per pixel
+    uint32_t* keep = key_scratch ? key_scratch + ((size_t)tile * 3 + j) * (size_t)g.pixels * (sizeof(T) >= 4 ? sizeof(T) / 4 : 1) : nullptr;
     GroupState& st = ws.state[tile];
     const PriorRecord* pr = &ws.prior[tile];
     const uint32_t below = get(&st.below[j]), spec = get(&st.spec);
@@ -1334,7 +1345,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
                 atomicAdd(&ws.state[0].slow_slots, 1u);
             }
             reset_scratch(&sh.t);
-            answer = select_whole_group<T>(images, g, tile, j, rank, v, use_all, &sh.t);
+            answer = select_whole_group<T>(images, g, tile, j, rank, v, use_all, &sh.t, keep);
         }
         if (threadIdx.x == 0) {
             put(&st.phi_key[j], answer);
@@ -1388,7 +1399,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     __syncthreads();
     if (__builtin_expect(sh.partner_ok == 0, 0)) {      // uniform; the partner never showed up: its percentile, the slow way
         reset_scratch(&sh.t);
-        const uint32_t partner_key = select_whole_group<T>(images, g, tile, 1 - j, rank_other, v, use_all, &sh.t);
+        const uint32_t partner_key = select_whole_group<T>(images, g, tile, 1 - j, rank_other, v, use_all, &sh.t, keep);
         __syncthreads();
         select_prepare(&sh);
         if (threadIdx.x == kWave) vectors_and_check(partner_key);
@@ -1445,7 +1456,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
             atomicAdd(&ws.state[0].slow_slots, 1u);
         }
         reset_scratch(&sh.t);
-        answer = select_whole_group<T>(images, g, tile, slot, k99, pinv, true, &sh.t);
+        answer = select_whole_group<T>(images, g, tile, slot, k99, pinv, true, &sh.t, keep);
     }
     if (threadIdx.x == 0) {
         const float mc = key_float(answer);
