@@ -111,7 +111,7 @@ struct Geometry {
     uint32_t over_cap;            // two-pass: ... and the tile's overflow area behind the segments holds this many
     int n_seg;                    // two-pass: segments per tile = waves of pass A per tile
     int spec_fail;                // diagnostic (SX_MACENKO_SPEC_FAIL): treat every speculation as failed -> the slow exact path
-    float spec_kw, spec_eff_far, spec_eff_near, spec_rot, spec_sigmas;      // two-pass: the speculation's knobs (macenko_twopass.hpp: kSpecKw ...)
+    float spec_kw, spec_eff_far, spec_eff_near, spec_rot, spec_sigmas, spec_sigmas_conc, spec_tscale;      // two-pass: the speculation's knobs (macenko_twopass.hpp: kSpecKw ...)
     int fused;                    // two-pass: pass A, the per-tile stages and the reconstruct pass in ONE launch (macenko_fused.hpp)
     int dense;                    // two-pass: candidates in dense record arrays (tiles up to 512 x 512) instead of a segment per wave
     uint32_t fused_cap;           // fused: candidate records per tile and slot
@@ -1284,6 +1284,26 @@ __device__ __forceinline__ void stats_item_all_pixels(const T* __restrict__ img,
     }
 }
 
+// A work item without kept pixels leaves the all-pixel sums only where the TILE may have fewer than three kept pixels.  Real slides
+// are full of work items that are pure background inside tiles that are mostly tissue (32 rows of a 512-wide tile; the reference's
+// example images: a third of the work items), and each paid a second sweep for sums nobody reads: 8 us of the 42 us moments pass on
+// a batch of real tiles.  A witness settles it: every thread looks at ONE pixel of the tile (TPB pixels spread evenly over it);
+// three kept ones among them prove that the tile has three kept pixels -- the same predicate on the same optical density, so there
+// is no false proof; a tile whose tissue the witnesses miss just does the sweep as before.  Workgroup-uniform result.
+template <typename T, int TPB, bool kInter>
+__device__ __forceinline__ bool tile_has_three_kept_witnesses(const T* __restrict__ img, int64_t pixels) {
+    const int64_t step = pixels / TPB > 0 ? pixels / TPB : 1;
+    const int64_t p = (int64_t)threadIdx.x * step + (int64_t)(((uint32_t)threadIdx.x * 0x9E3779B1u) >> 16) % step;
+    int kept = 0;
+    if (p < pixels) {
+        float v[3][1];
+        load_pixels<T, 1, kInter>(img, pixels, p, v);
+        const float od[3] = {optical_density<T>(v[0][0]), optical_density<T>(v[1][0]), optical_density<T>(v[2][0])};
+        kept = od_selected(od, false) ? 1 : 0;
+    }
+    return __syncthreads_count(kept) >= 3;
+}
+
 template <typename T, int V, int TPB, bool kInter>
 __device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh, const LevelTables<T>& tb) {
     const int64_t p_begin = (int64_t)chunk_id * g.chunk;
@@ -1379,7 +1399,9 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     double kept = 0.0;
 #pragma unroll
     for (int w = 0; w < TPB / kWave; ++w) kept += sh->red[w][0];      // workgroup-uniform
-    if (__builtin_expect(kept < 3.0, 0)) stats_item_all_pixels<T, V, TPB, kInter>(img, g.pixels, p_begin, p_end, ws.partial_all + item * kPartial, sh);
+    if (__builtin_expect(kept < 3.0, 0)) {
+        if (!tile_has_three_kept_witnesses<T, TPB, kInter>(img, g.pixels)) stats_item_all_pixels<T, V, TPB, kInter>(img, g.pixels, p_begin, p_end, ws.partial_all + item * kPartial, sh);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2668,6 +2690,8 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
         g.spec_eff_near = kSpecEffNear;
         g.spec_rot = kSpecRot;
         g.spec_sigmas = kSpecSigmas;
+        g.spec_sigmas_conc = kSpecSigmasConc;
+        g.spec_tscale = kSpecThresholdScale;
 #ifdef SX_STAMPS      // diagnostic builds only: the knobs from the environment (tools/sweep_real.py under tools/tune_spec.sh)
         auto knob = [](const char* name, float& v) { if (const char* e = std::getenv(name)) v = (float)std::atof(e); };
         knob("SX_SPEC_KW", g.spec_kw);
@@ -2675,6 +2699,8 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
         knob("SX_SPEC_EFF_NEAR", g.spec_eff_near);
         knob("SX_SPEC_ROT", g.spec_rot);
         knob("SX_SPEC_SIGMAS", g.spec_sigmas);
+        knob("SX_SPEC_SIGMAS_CONC", g.spec_sigmas_conc);
+        knob("SX_SPEC_TSCALE", g.spec_tscale);
 #endif
         g.fused_cap = fused_cap_for(g.pixels);
         g.fused_items = (int)(g.n_tiles * g.blocks_per_tile);

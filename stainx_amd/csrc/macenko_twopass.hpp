@@ -43,6 +43,7 @@ namespace macenko {
 constexpr int kPriorSweeps = 4;                       // 4-pixel quads a thread of the prior stage samples
 constexpr int kPriorUnitsMax = kGroupThreads / 4 * kPriorSweeps;      // sectors of 16 pixels per tile: 1024
 constexpr int kQueue2 = 512;                          // 16-byte records a wave queues in LDS before it must flush
+constexpr float kSpecSigmasConc = 5.0f, kSpecThresholdScale = 1.0f;      // the concentration thresholds: their quantile's distance below 99 % in standard deviations, and a factor on them
 constexpr float kSpecSigmas = 5.0f;                   // half-width of a bracket in standard deviations of the sample quantile
 // Independent samples per 16-pixel sector (four of its pixels enter the histograms: neighbours).  Sectors far apart -- at least
 // 8 sector lengths between sampled ones: tiles from ~360x360 -- are taken for TWO (sweeps over 3840 tiles of 512x512 / 256x256 and
@@ -477,10 +478,10 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
     SX_STAMP(st, 6);
     if (wave < 4) {
         const float n_eff = fmaxf((float)ms * (spec_eff(g) / 4.0f), 4.0f);
-        const float level = 0.99f - g.spec_sigmas * sqrtf(0.99f * 0.01f / n_eff);
+        const float level = 0.99f - g.spec_sigmas_conc * sqrtf(0.99f * 0.01f / n_eff);
         const uint32_t rank = (uint32_t)max((int)floorf(fmaxf(level, 0.0f) * (float)max(ms - 1, 0)), 0);
         const uint32_t b = prior_pick_bin(sh.hist[wave], rank);
-        if (lane == 0) sh.cthr[wave] = (level > 0.0f && b > 0) ? (float)b * (r_max / (float)kPriorBins) : -__builtin_huge_valf();      // the bin's lower edge
+        if (lane == 0) sh.cthr[wave] = (level > 0.0f && b > 0) ? g.spec_tscale * (float)b * (r_max / (float)kPriorBins) : -__builtin_huge_valf();      // the bin's lower edge
     }
     __syncthreads();
     if (tid < 9) {      // one test row per thread (compile-time indices: a run-time index would send bd / cu to scratch memory)
@@ -822,8 +823,10 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
     for (int w = 0; w < TPB / kWave; ++w) kept_total += ss->red[w][0];      // workgroup-uniform
     // (see stats_item: a work item without kept pixels also leaves the moments of ALL its pixels)
     if (__builtin_expect(kept_total < 3.0, 0)) {
-        stats_item_all_pixels<T, V, TPB, kInter>(img, g.pixels, p_begin, p_end, ws.partial_all + item * kPartial, ss);
-        if constexpr (kFused) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (plain stores in there: written back before the flag below; rare path)
+        if (!tile_has_three_kept_witnesses<T, TPB, kInter>(img, g.pixels)) {      // (see there: only where the TILE may be blank)
+            stats_item_all_pixels<T, V, TPB, kInter>(img, g.pixels, p_begin, p_end, ws.partial_all + item * kPartial, ss);
+            if constexpr (kFused) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (plain stores in there: written back before the flag below; rare path)
+        }
     }
     if constexpr (kFused) {
         // publish: every wave has drained its write-through stores and atomics, then ONE lane counts the work item in

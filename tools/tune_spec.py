@@ -35,8 +35,9 @@ def timed(x, flags, steps=60, warm=10):
     return e0.elapsed_time(e1) / steps * 1e3
 
 
-grid = [dict(zip(("SX_SPEC_KW", "SX_SPEC_ROT", "SX_SPEC_EFF_FAR", "SX_SPEC_SIGMAS"), v)) for v in
-        [(0.05, 0.04, 2.0, 5.0), (0.10, 0.3, 2.0, 5.0), (0.15, 0.3, 2.0, 5.0), (0.15, 0.3, 1.0, 5.0), (0.20, 0.3, 1.0, 5.0), (0.15, 0.3, 0.5, 5.0), (0.25, 0.3, 0.5, 5.0), (0.15, 0.3, 1.0, 7.0)]]
+grid = [dict(zip(("SX_SPEC_KW", "SX_SPEC_ROT", "SX_SPEC_EFF_FAR", "SX_SPEC_SIGMAS", "SX_SPEC_SIGMAS_CONC", "SX_SPEC_TSCALE"), v)) for v in
+        [(0.10, 0.3, 2.0, 5.0, 5.0, 1.0), (0.10, 0.3, 2.0, 5.0, 8.0, 1.0), (0.10, 0.3, 2.0, 5.0, 12.0, 1.0), (0.10, 0.3, 2.0, 5.0, 5.0, 0.97), (0.10, 0.3, 2.0, 5.0, 5.0, 0.94),
+         (0.10, 0.3, 2.0, 5.0, 8.0, 0.94), (0.10, 0.3, 2.0, 4.0, 8.0, 0.94), (0.12, 0.3, 2.0, 4.0, 12.0, 0.90)]]
 out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
 for knobs in grid:
     for k, v in knobs.items(): os.environ[k] = str(v)
