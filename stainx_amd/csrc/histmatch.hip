@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const T* __restrict__ i
     const int64_t stride = (int64_t)gridDim.x * kThreads * V;
     for (int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * V; e < total; e += stride) {
         if constexpr (kVec) {
-            const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(images + e);
+            const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(images + e);      // (non-temporal loads here: no gain over rotating batches, 3 us lost on one buffer -- tools/ab_rotating_siblings.py)
             Pack<T, V> res;
             int c = lay.channel_of(e);
 #pragma unroll

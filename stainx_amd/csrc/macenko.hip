@@ -1637,7 +1637,24 @@ __device__ __forceinline__ void reconstruct_item(const T* __restrict__ images, O
 
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)TPB * V) {
         float u[3][V];
-        load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p, u);
+        // This pass is the call's LAST reader of the input: planar 16-byte packs are loaded non-temporally (they then leave no lines
+        // behind in the L2s for the pass's own stores to push out: reconstruct 65.3 -> 61.5 us and the call 0.1733 -> 0.1657 ms per
+        // step in bench.py's rotation over two batches; measured A/B on one box, profiles/r03_reconstruct_nt_loads_ab.txt)
+        if constexpr (!kInter && sizeof(T) * V == 16) {
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const u4v q = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(img + c * g.pixels + p));
+                Pack<T, V> pk;
+                __builtin_memcpy(&pk, &q, 16);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    if constexpr (sizeof(T) == 1) u[c][i] = __uint_as_float((uint32_t)pk.v[i]); else u[c][i] = raw_value<T>(pk.v[i]);
+                }
+            }
+        } else {
+            load_pixels<T, V, kInter, sizeof(T) == 1>(img, g.pixels, p, u);
+        }
         O res[3][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {

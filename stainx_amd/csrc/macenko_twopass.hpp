@@ -688,11 +688,11 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
             const PixelPacks<T, V, kInter> u = next;
             const int64_t p_next = base_p + (int64_t)TPB * V + mine;
             if (p_next < p_end) next.load(img, g.pixels, p_next);
-            const uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
+            uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
+            asm volatile("" : "+s"(live_mask));      // (opaque: otherwise the comparison behind it is redone for every pixel of the pack -- a 64-bit add and a 64-bit compare each time)
 #pragma unroll
             for (int i0 = 0; i0 < V; i0 += G) {
                 float od[G][3];
-                bool kept[G];
                 uint64_t valid[G];
                 float16v forms[G];
 #pragma unroll
@@ -700,9 +700,10 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
 #pragma unroll
                     for (int c = 0; c < 3; ++c) od[gi][c] = od_of<T>(u.value(c, i0 + gi), tb);
                     const bool sel = od_selected(od[gi], false);
-                    kept[gi] = live && sel;
                     valid[gi] = __builtin_amdgcn_ballot_w64(sel) & live_mask;      // (the ballot of a bare comparison is the comparison's own mask; of `live && sel` it is a 0 / 1 register compared with 0 again)
-                    if (kept[gi]) {      // (stats_item multiplies by a 0 / 1 `keep` instead: the same bits, four instructions more)
+                    // (the lanes of `valid` as the branch's mask: `live && sel` made the compiler work `live` out again for every pixel --
+                    // a 64-bit add and a 64-bit compare -- because the comparison's result does not survive in vcc)
+                    if (__builtin_amdgcn_inverse_ballot_w64(valid[gi])) {      // (stats_item multiplies by a 0 / 1 `keep` instead: the same bits, four instructions more)
                         const float* o = od[gi];
                         m[0] += 1.0f;
                         m[1] += o[0];

@@ -85,6 +85,19 @@ template <typename T, int V>
 __device__ __forceinline__ void load_for_lab(const T* __restrict__ p, float (&out)[V]) {
     if constexpr (sizeof(T) == 1) load_raw<T, V>(p, out); else load_unit<T, V>(p, out);
 }
+// the same for the apply pass, the call's last reader of the input: non-temporal packs (common.hpp: load_pack_stream)
+template <typename T, int V>
+__device__ __forceinline__ void load_for_lab_last(const T* __restrict__ p, float (&out)[V]) {
+    if constexpr (V == 1) {
+        load_for_lab<T, V>(p, out);
+    } else {
+        const Pack<T, V> pk = load_pack_stream<T, V>(p);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            if constexpr (sizeof(T) == 1) out[i] = raw_value<T>(pk.v[i]); else out[i] = Elem<T>::load(pk.v[i]);
+        }
+    }
+}
 
 __device__ __forceinline__ float f_inv(float t) { return t > 0.2068966f ? t * t * t : (t - 16.0f / 116.0f) * (1.0f / 7.787f); }   // :78-80
 
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restri
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
         float u[3][V];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) load_for_lab<T, V>(img + c * g.pixels + p, u[c]);
+        for (int c = 0; c < 3; ++c) load_for_lab_last<T, V>(img + c * g.pixels + p, u[c]);
         T res[3][V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {

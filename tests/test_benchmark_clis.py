@@ -31,36 +31,31 @@ def _run(mod, argv, capsys):
     return rc, io.out, io.err
 
 
+def _help_text(mod) -> str:
+    import contextlib
+    import io
+
+    buf = io.StringIO()
+    old = sys.argv
+    sys.argv = [mod.__name__, "--help"]
+    try:
+        with contextlib.redirect_stdout(buf), pytest.raises(SystemExit) as exc:
+            mod.main()
+        assert exc.value.code == 0
+    finally:
+        sys.argv = old
+    return buf.getvalue()
+
+
 def test_cli_flags_are_the_references(capsys):
     grid, single = _load("benchmark_stainx_amd_grid"), _load("run_stainx_amd")
     for mod, flags in ((grid, ("--method", "--image-size", "--channels", "--warmup", "--runs", "--seed", "--batch-size", "--backend1", "--backend2")),
                        (single, ("--batch-size", "--height", "--width", "--channels", "--device", "--runs", "--seed"))):
-        with pytest.raises(SystemExit) as exc:
-            _run(mod, ["--help"], capsys)
-        assert exc.value.code == 0
+        text = _help_text(mod)
+        for f in flags:
+            assert f in text, (mod.__name__, f)
     with pytest.raises(SystemExit):
         _run(grid, [], capsys)                                   # --method is required, as in the reference
-    help_text = {}
-    for mod in (grid, single):
-        try:
-            _run(mod, ["--help"], capsys)
-        except SystemExit:
-            pass
-    # (argparse prints --help before exiting: read it back through a fresh parse)
-    import contextlib, io
-
-    for mod, flags in ((grid, ("--method", "--image-size", "--channels", "--warmup", "--runs", "--seed", "--batch-size", "--backend1", "--backend2")),
-                       (single, ("--batch-size", "--height", "--width", "--channels", "--device", "--runs", "--seed"))):
-        buf = io.StringIO()
-        sys_argv = sys.argv
-        sys.argv = [mod.__name__, "--help"]
-        try:
-            with contextlib.redirect_stdout(buf), pytest.raises(SystemExit):
-                mod.main()
-        finally:
-            sys.argv = sys_argv
-        for f in flags:
-            assert f in buf.getvalue(), (mod.__name__, f)
     rc, _, err = _run(single, ["macenko", "--device", "cpu"], capsys)
     assert rc == 2 and "not supported" in err                    # no CPU path in this package
 
