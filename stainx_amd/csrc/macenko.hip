@@ -2972,7 +2972,11 @@ extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, in
 extern "C" int sx_macenko_form(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) {
     if (n <= 0 || h <= 0 || w <= 0 || (flags & SX_MACENKO_SAMPLED)) return 0;
     const int64_t pixels = h * w;
-    const bool pays = (dtype == SX_F32 || dtype == SX_F64) && pixels >= 16384 && pixels <= (1ll << 19) && n * pixels >= (1ll << 22);
+    // (narrow pixels -- uint8 / f16 / bf16 -- since the candidates travel as dense records: tiles of ~360 x 360 ... 512 x 512, where the
+    // two-pass form saves two instruction-bound passes -- uint8 64 x 512 x 512: 106 us against 118, bf16 126 against 144; at 320 x 320 and
+    // below, and on the per-wave segments of larger tiles, the four passes win: tools/bench_twopass.py, profiles/r03_forms_by_dtype_and_tile.jsonl)
+    const bool wide = dtype == SX_F32 || dtype == SX_F64;
+    const bool pays = n * pixels >= (1ll << 22) && (wide ? (pixels >= 16384 && pixels <= (1ll << 19)) : (pixels >= 131072 && pixels <= 262144));
     const bool wanted = (flags & SX_MACENKO_TWO_PASS) != 0 || (pays && !(flags & SX_MACENKO_CLASSIC));
     if (!(wanted && two_pass_size(pixels))) return 0;
     const bool fusable = (flags & SX_MACENKO_FUSE) != 0 && dtype == SX_F32 && fused_size(pixels) && !(flags & SX_MACENKO_CHANNELS_LAST);

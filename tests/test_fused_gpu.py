@@ -156,7 +156,8 @@ def test_workspace_sizes_per_form():
     mb = 1 << 20
     bf16, u8 = _native.DTYPE_CODES[torch.bfloat16], _native.DTYPE_CODES[torch.uint8]
     assert lib.sx_macenko_workspace_bytes_for(bf16, 256, 224, 224, 0) <= 60 * mb
-    assert lib.sx_macenko_workspace_bytes_for(u8, 64, 512, 512, 0) <= 60 * mb
+    assert lib.sx_macenko_workspace_bytes_for(u8, 64, 512, 512, _native.MACENKO_CLASSIC) <= 60 * mb
+    assert lib.sx_macenko_workspace_bytes_for(u8, 64, 512, 512, 0) <= 120 * mb      # (takes the two-pass form now: + its dense candidate records)
     assert lib.sx_macenko_workspace_bytes_for(F32, 64, 512, 512, 0) <= 120 * mb
     assert lib.sx_macenko_workspace_bytes_for(F32, 64, 512, 512, FUSED) <= 120 * mb
     assert lib.sx_macenko_workspace_bytes_for(F32, 64, 512, 512, _native.MACENKO_CLASSIC) < lib.sx_macenko_workspace_bytes_for(F32, 64, 512, 512, 0)

@@ -136,11 +136,12 @@ def test_default_route_and_feedback(be, dev):
     assert fresh._classic_left > 0 and _same(first, second)
     classic = fresh.transform(xb, SM, TMC, _extra_flags=_native.MACENKO_CLASSIC)
     assert _same(first, classic)
-    # calls the library runs in its four-pass form anyway (small batches, narrow pixels) take no part in the feedback: no event, no
-    # side-stream copy (7 us of host time on a launch-bound call)
+    # calls the library runs in its four-pass form anyway (small batches, narrow pixels on small tiles) take no part in the feedback:
+    # no event, no side-stream copy (7 us of host time on a launch-bound call)
     quiet = MacenkoHIP(dev)
     quiet.transform(x[:1].contiguous(), SM, TMC)
-    quiet.transform(synth.as_dtype(tiles, torch.uint8).to(dev), SM, TMC)
+    quiet.transform(synth.as_dtype(tiles[:8], torch.uint8).to(dev), SM, TMC)
+    quiet.transform(synth.as_dtype(synth.he_batch(96, 224, 224, seed0=5), torch.bfloat16).to(dev), SM, TMC)
     assert quiet._tele_event is None and quiet._tele_stream is None
 
 
