@@ -43,6 +43,8 @@ def force_collectives() -> bool:
 
 # bench.py --workload fit_transform_pooled: device time spent inside the collectives (HIP events around every dist call)
 _TIMED: list | None = None
+# _macenko_fit_pooled_brackets: the ranks' tile counts of the last call per (group, local shape): ([counts], the same on the device)
+_TILE_COUNTS: dict = {}
 
 
 class collective_timer:
@@ -155,6 +157,7 @@ def macenko_fit_transform_pooled(local_images: torch.Tensor, *, group=None, step
     he, max_c, pending = _macenko_fit_pooled(local_images, group, steps, method, defer_status=True)
     out = steps.transform(local_images, he, max_c, normalize_to_0_1=normalize_to_0_1)
     if pending is not None and not pending():
+        _TILE_COUNTS.clear()      # (a stale sharding may be why: the repeat reads the counts afresh)
         he, max_c, _ = _macenko_fit_pooled(local_images, group, steps, "radix", defer_status=False)
         out = steps.transform(local_images, he, max_c, normalize_to_0_1=normalize_to_0_1)
     return out, he, max_c
@@ -194,8 +197,12 @@ def _macenko_fit_pooled(local_images, group, steps, method: str, defer_status: b
             return he, max_c, held
         # the same on every rank by construction (every rank ran the same selection on the same union), so the decision to
         # repeat with the radix rounds is collective without another exchange
-        if int(status.item()) == 0:
+        code = int(status.item())
+        if code == 0:
             return he, max_c, None
+        if code & 2:      # the cached tile counts were stale: once more with fresh ones (still the bracket form)
+            _TILE_COUNTS.clear()
+            return _macenko_fit_pooled(local_images, group, steps, method, defer_status)
     else:
         # (both methods: a rank without tiles must fail on EVERY rank here, not leave the others in the next collective)
         tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
@@ -235,7 +242,20 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _shar
         mine = torch.cat([torch.full((1,), int(n), dtype=torch.int64, device=moments.device).view(torch.uint8), moments.contiguous().view(torch.uint8),
                           sample.contiguous().view(torch.uint8).flatten()])
         got = all_gather_stack(mine, group)                                                   # (world, 8 + 80 + 49152)
-        tiles = [int(v) for v in got[:, :8].contiguous().view(torch.int64).flatten().tolist()]      # the step's one early host read (only the first pass is queued)
+        counts_dev = got[:, :8].contiguous().view(torch.int64).flatten()
+        # The ranks' tile counts are needed on the HOST (pixel total, sample layout, the compact list's split), and reading them
+        # stalls the host until the first pass has run -- with ~20 launches still to queue behind it.  A loop calls this with the same
+        # sharding step after step: the counts of the last call with this (group, local shape) are taken on trust and CHECKED ON THE
+        # DEVICE against what the all-gather brought (folded into the status word the caller reads after everything is queued; a
+        # mismatch -- some rank's shard changed -- repeats the fit with fresh counts).
+        key = (id(group) if group is not None else 0, int(n), int(h), int(w), int(counts_dev.numel()), str(counts_dev.device))
+        cached = _TILE_COUNTS.get(key) if int(n) > 0 else None
+        if cached is not None:
+            tiles, stale = cached[0], (counts_dev != cached[1]).any().to(torch.int32).reshape(1)
+        else:
+            tiles, stale = [int(v) for v in counts_dev.tolist()], None      # (the one early host read: only the first pass is queued)
+            if min(tiles) > 0:
+                _TILE_COUNTS[key] = (tiles, counts_dev.clone())
         if min(tiles) <= 0:
             raise ValueError(f"every rank needs at least one tile for a pooled statistic, got tiles per rank {tiles} (shard with shard_bounds over >= world_size tiles)")
         size = len(tiles)
@@ -256,15 +276,24 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _shar
     steps.pfit_plane(moments, n_all, union, sample_count, shape)
     share = int(_share) if _share else 32768 // size          # every rank's part of the compact candidate list (_share: tests mimic a larger world)
     out = None
+    any_stale = None
     for stage in (0, 1):
         sums = all_reduce_sum(steps.pfit_pass(local_images, stage, n_all, sample_count), group)
         compact, counts = steps.pfit_gather(sums, stage, n_all, sample_count, shape, share)
         if skip:
             g_compact, g_counts = compact.unsqueeze(0), counts.unsqueeze(0)
-        else:      # the two counts travel in front of the keys: one exchange
-            got = all_gather_stack(torch.cat([counts.to(torch.int32).flatten(), compact.to(torch.int32).flatten()]), group)
-            g_counts, g_compact = got[:, :2], got[:, 2:].reshape(size, 2, share)
+        else:
+            # the two counts travel in front of the keys: one exchange.  So does this rank's "my cached tile counts were stale" flag:
+            # every rank sees every rank's, so the decision to repeat the fit is the same everywhere (a rank that repeated alone
+            # would leave the others out of its collectives).
+            flag = stale.to(counts.device) if stale is not None else torch.zeros(1, dtype=torch.int32, device=counts.device)
+            got = all_gather_stack(torch.cat([counts.to(torch.int32).flatten(), flag.to(torch.int32), compact.to(torch.int32).flatten()]), group)
+            g_counts, g_compact = got[:, :2], got[:, 3:].reshape(size, 2, share)
+            any_stale = got[:, 2].max().reshape(1)
         out = steps.pfit_finish(g_compact, g_counts, stage, n_all, sample_count, shape)
+    if any_stale is not None:
+        he, max_c, status = out
+        out = (he, max_c, status + 2 * any_stale.to(device=status.device, dtype=status.dtype))      # (bit 1: some rank's cached tile counts were not this call's)
     return out
 
 

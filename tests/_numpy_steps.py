@@ -164,7 +164,9 @@ class NumpyMacenkoBracketSteps(NumpyMacenkoSteps):
         st["want"] = [0, 0]
         for j in range(2):
             want = st["rank"][2 * stage + j] - int(g[1024 + 2 * stage + j])
-            assert 0 <= want < int(g[1028 + 2 * stage + j]), "bracket missed in the stand-in"
+            if not 0 <= want < int(g[1028 + 2 * stage + j]):      # a bracket missed: reported through the status word, like the native steps
+                st["missed"] = True
+                want = 0
             cum = np.cumsum(g[stage * 512 + j * 256: stage * 512 + (j + 1) * 256])
             b = int(np.searchsorted(cum, want, side="right"))
             st["want"][j] = want - (int(cum[b - 1]) if b else 0)
@@ -179,7 +181,10 @@ class NumpyMacenkoBracketSteps(NumpyMacenkoSteps):
         keys = []
         for j in range(2):
             parts = [gathered_compact[r, j, : int(gathered_counts[r, j])].numpy().view(np.uint32) for r in range(gathered_counts.shape[0])]
-            keys.append(int(np.sort(np.concatenate(parts))[st["want"][j]]))
+            merged = np.sort(np.concatenate(parts))
+            if st["want"][j] >= len(merged):
+                st["missed"] = True
+            keys.append(int(merged[min(st["want"][j], len(merged) - 1)]) if len(merged) else 0)
         if stage == 0:
             st["he"] = so.stain_vectors_from_angles(st["vecs"], key_float(keys[0]), key_float(keys[1]))
             st["pinv"] = np.linalg.pinv(st["he"].astype(np.float64)).astype(np.float32)
@@ -191,7 +196,7 @@ class NumpyMacenkoBracketSteps(NumpyMacenkoSteps):
                 st["brackets"].append(tuple(int(ks[i]) for i in _bracket_ranks(len(ks), n_all, st["rank"][2 + j])))
             return None
         max_c = np.array([key_float(keys[0]), key_float(keys[1])], dtype=np.float32)
-        return torch.from_numpy(st["he"].copy()), torch.from_numpy(max_c), torch.zeros(1, dtype=torch.int32)
+        return torch.from_numpy(st["he"].copy()), torch.from_numpy(max_c), torch.full((1,), 1 if st.get("missed") else 0, dtype=torch.int32)
 
 
 def keys_to_float(keys: np.ndarray) -> np.ndarray:

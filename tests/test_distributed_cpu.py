@@ -140,3 +140,39 @@ def _forced_worker(rank: int, world_size: int, port: int, out_dir: str):
 def test_forced_collectives_at_world_size_one(tmp_path):
     mp.spawn(_forced_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     assert bool(np.load(tmp_path / "forced.npz")["same"])
+
+
+def _resharded_worker(rank: int, world_size: int, port: int, out_dir: str):
+    """Two calls with the same local shape on rank 0 while rank 1's shard shrinks: rank 0's cached tile counts are stale in the second
+    call; the flag travels with the stage exchange, so BOTH ranks repeat the fit (nobody is left alone in a collective) and the
+    result is the one of the new sharding."""
+    from tests._numpy_steps import NumpyMacenkoBracketSteps
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        sxd._TILE_COUNTS.clear()
+        tiles = synth.he_batch(5, 48, 48, seed0=31)
+        first = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:5], steps=NumpyMacenkoBracketSteps())
+        cached_after_first = len(sxd._TILE_COUNTS)
+        second = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:4], steps=NumpyMacenkoBracketSteps())      # rank 1: one tile now
+        third = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:4], steps=NumpyMacenkoBracketSteps())       # (cached again, and right)
+        np.savez(os.path.join(out_dir, f"reshard{rank}.npz"), he1=first[0].numpy(), he2=second[0].numpy(), mc2=second[1].numpy(), he3=third[0].numpy(), cached=cached_after_first)
+    finally:
+        sxd._TILE_COUNTS.clear()
+        dist.destroy_process_group()
+
+
+def test_cached_tile_counts_are_checked_collectively(tmp_path):
+    mp.spawn(_resharded_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "reshard0.npz"), np.load(tmp_path / "reshard1.npz")
+    assert int(r0["cached"]) == 1
+    tiles = synth.he_batch(5, 48, 48, seed0=31)
+    he5, _ = so.macenko_fit(tiles.numpy(), signs="positive_sum")
+    he4, mc4 = so.macenko_fit(tiles[:4].numpy(), signs="positive_sum")
+    for r in (r0, r1):
+        np.testing.assert_allclose(r["he1"], he5, atol=2e-5)
+        np.testing.assert_allclose(r["he2"], he4, atol=2e-5)          # the NEW sharding's estimate, although rank 0's cache said [3, 2]
+        np.testing.assert_allclose(r["mc2"], mc4, rtol=2e-5)
+        np.testing.assert_array_equal(r["he3"], r["he2"])
+    np.testing.assert_array_equal(r0["he2"], r1["he2"])
