@@ -2965,7 +2965,8 @@ extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, in
 
 // Which form sx_macenko_transform takes for a call: 0 the four passes, 1 the two-pass form as four launches, 2 the two-pass form
 // with pass A, the stage jobs and the reconstruct pass fused into one launch.  Where the two-pass form pays (measured,
-// tools/bench_twopass.py): 4- and 8-byte pixels in batches of at least ~4 M pixels and tiles up to ~724 x 724.  Narrow pixels
+// tools/bench_twopass.py, tools/survey_forms.py): 4- and 8-byte pixels in batches of at least ~4 M pixels and tiles of ~192 x 192 ... 724 x 724
+// (1024 tiles of 128 x 128: 367 us in four passes against 411).  Narrow pixels
 // (uint8 / bf16 / f16) make the four passes cheap -- the forms are level there --, big tiles put tens of thousands of candidates on
 // one stage workgroup.  The fused launch serves planar float32 tiles of 128 x 128 ... 512 x 512 pixels.  SX_MACENKO_TWO_PASS asks
 // for the two-pass form wherever it is able to run (tests, A/B runs); SX_MACENKO_NO_FUSE keeps it to four launches.
@@ -2976,7 +2977,7 @@ extern "C" int sx_macenko_form(int dtype, int64_t n, int64_t h, int64_t w, unsig
     // two-pass form saves two instruction-bound passes -- uint8 64 x 512 x 512: 106 us against 118, bf16 126 against 144; at 320 x 320 and
     // below, and on the per-wave segments of larger tiles, the four passes win: tools/bench_twopass.py, profiles/r03_forms_by_dtype_and_tile.jsonl)
     const bool wide = dtype == SX_F32 || dtype == SX_F64;
-    const bool pays = n * pixels >= (1ll << 22) && (wide ? (pixels >= 16384 && pixels <= (1ll << 19)) : (pixels >= 131072 && pixels <= 262144));
+    const bool pays = n * pixels >= (1ll << 22) && (wide ? (pixels >= 36864 && pixels <= (1ll << 19)) : (pixels >= 131072 && pixels <= 262144));
     const bool wanted = (flags & SX_MACENKO_TWO_PASS) != 0 || (pays && !(flags & SX_MACENKO_CLASSIC));
     if (!(wanted && two_pass_size(pixels))) return 0;
     const bool fusable = (flags & SX_MACENKO_FUSE) != 0 && dtype == SX_F32 && fused_size(pixels) && !(flags & SX_MACENKO_CHANNELS_LAST);

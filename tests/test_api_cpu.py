@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     takes = _native.require().sx_macenko_takes_two_pass
     f32, u8, bf16 = _native.DTYPE_CODES[torch.float32], _native.DTYPE_CODES[torch.uint8], _native.DTYPE_CODES[torch.bfloat16]
     assert takes(f32, 64, 512, 512, 0) == 1 and takes(_native.DTYPE_CODES[torch.float64], 64, 512, 512, 0) == 1
-    assert takes(f32, 1, 512, 512, 0) == 0 and takes(f32, 4, 2048, 2048, 0) == 0 and takes(f32, 1024, 64, 64, 0) == 0
+    assert takes(f32, 1, 512, 512, 0) == 0 and takes(f32, 4, 2048, 2048, 0) == 0 and takes(f32, 1024, 64, 64, 0) == 0 and takes(f32, 1024, 128, 128, 0) == 0
     assert takes(u8, 64, 512, 512, 0) == 1 and takes(bf16, 64, 384, 384, 0) == 1      # narrow pixels: tiles of ~360 x 360 ... 512 x 512 (round 3: dense candidate records)
     assert takes(bf16, 256, 224, 224, 0) == 0 and takes(u8, 164, 320, 320, 0) == 0 and takes(u8, 36, 724, 724, 0) == 0 and takes(u8, 4, 512, 512, 0) == 0
     assert takes(f32, 64, 512, 512, _native.MACENKO_CLASSIC) == 0 and takes(f32, 64, 512, 512, _native.MACENKO_SAMPLED) == 0
