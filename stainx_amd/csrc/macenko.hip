@@ -98,6 +98,7 @@ struct Geometry {
     int distributed;              // 1: the group also spans other ranks (sx_macenko_pfit_*): totals come from the host, no local fallback
     long long n_all;              // distributed: pixels of the whole group over all ranks
     int fine_chunk, fine_blocks;  // small batches: pixels per work item / work items per tile of the bracket and reconstruct stages (0: kChunk)
+    int recon_chunk, recon_blocks; // reconstruct stage: pixels per work item / work items per tile when it splits finer than the other stages (0: as them)
     int fast;                     // precision="fast": sample percentiles instead of the exact ones
     int chunk;                    // pixels per work item: the tile split evenly over its blocks_per_tile work items (<= kChunk)
     int vec_width;                // pixels per 16-byte pack of the element type (host side, for the chunk rounding)
@@ -1589,7 +1590,7 @@ __device__ void bracket_item(const T* __restrict__ images, const Geometry& g, co
 template <typename T, typename O, int V, bool kUnit, int TPB, bool kInter>
 __device__ __forceinline__ void reconstruct_item(const T* __restrict__ images, O* __restrict__ out, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id,
                                  const float* __restrict__ stain_matrix, const LevelTables<T>& tb, uint4* __restrict__ stage = nullptr, const float* __restrict__ given = nullptr) {
-    const int64_t chunk = g.fine_chunk ? g.fine_chunk : g.chunk;
+    const int64_t chunk = g.recon_chunk ? g.recon_chunk : (g.fine_chunk ? g.fine_chunk : g.chunk);
     const int64_t p_begin = (int64_t)chunk_id * chunk;
     const int64_t p_end = min(p_begin + chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
@@ -2374,7 +2375,7 @@ __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __rest
 
 template <typename T, typename O, int V, bool kUnit, bool kInter = false>
 __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __restrict__ images, O* __restrict__ out, Geometry g, Workspace ws, const float* __restrict__ stain_matrix) {
-    const int per_tile = g.fine_chunk ? g.fine_blocks : g.blocks_per_tile;
+    const int per_tile = g.recon_chunk ? g.recon_blocks : (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile);
     __shared__ LevelTables<T> tb;
     tb.fill();
     const unsigned item = blockIdx.x;      // (measured: reversing the order, so that the work items pass A touched last come first, changes nothing)
@@ -2659,7 +2660,7 @@ static int run_fused(const T* images, O* out, const Geometry& g, const Workspace
 
 template <typename T, typename O, int V, bool kInter = false>
 static int run_transform(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
-    const unsigned items = (unsigned)(g.n_tiles * (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile));
+    const unsigned items = (unsigned)(g.n_tiles * (g.recon_chunk ? g.recon_blocks : (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile)));      // reconstruct work items
     int rc = SX_OK;
     if (g.fast) {
         hipLaunchKernelGGL((stats_kernel<T, V, kInter>), dim3((unsigned)(g.n_tiles * g.blocks_per_tile)), dim3(kStreamThreads), 0, stream, images, g, ws);
@@ -2678,10 +2679,20 @@ static int run_transform(const T* images, O* out, const Geometry& g, const Works
     // type leaves every lane 64-192 bytes of its own and every store instruction 64 different lines: uint8 -> float32 (/255)
     // took 172 us planar and 569 us NHWC for the config-2 batch where the same-width uint8 output takes 24 us.
     constexpr int VR = V == 1 ? 1 : ((int)(16 / sizeof(O)) < V ? (int)(16 / sizeof(O)) : V);
+    // Big batches: ONE pack set per thread and work item (no loop: 16384 small workgroups for config 2 instead of 1024 of sixteen
+    // sweeps -- the pass has no per-item state, and with 1024 workgroups only half the waves a CU can hold were resident: call
+    // 159.2 -> 156.1 us, tools/ab_recon_chunk.py).  Small batches keep their own split (fine_chunk).
+    Geometry gr = g;
+    unsigned items_r = items;
+    if (!g.recon_chunk && !g.fine_chunk && V > 1 && g.n_tiles * g.pixels >= (1ll << 22)) {
+        gr.recon_chunk = kStreamThreads * VR;
+        gr.recon_blocks = (int)((g.pixels + gr.recon_chunk - 1) / gr.recon_chunk);
+        items_r = (unsigned)(g.n_tiles * gr.recon_blocks);
+    }
     if (unit)
-        hipLaunchKernelGGL((reconstruct_kernel<T, O, VR, true, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
+        hipLaunchKernelGGL((reconstruct_kernel<T, O, VR, true, kInter>), dim3(items_r), dim3(kStreamThreads), 0, stream, images, out, gr, ws, sm);
     else
-        hipLaunchKernelGGL((reconstruct_kernel<T, O, VR, false, kInter>), dim3(items), dim3(kStreamThreads), 0, stream, images, out, g, ws, sm);
+        hipLaunchKernelGGL((reconstruct_kernel<T, O, VR, false, kInter>), dim3(items_r), dim3(kStreamThreads), 0, stream, images, out, gr, ws, sm);
     return check_launch("macenko reconstruct");
 }
 
@@ -2744,6 +2755,15 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
             g.fine_blocks = (int)((g.pixels + chunk - 1) / chunk);
         }
     }
+#ifdef SX_STAMPS      // diagnostic builds: the reconstruct stage's work-item size from the environment (tools: A/B of its grid)
+    if (const char* e = std::getenv("SX_RECON_CHUNK")) {
+        const int64_t c = std::atoll(e);
+        if (c > 0 && !g.fused && c % ((int64_t)kStreamThreads * (vec ? W : 1)) == 0) {
+            g.recon_chunk = (int)c;
+            g.recon_blocks = (int)((g.pixels + c - 1) / c);
+        }
+    }
+#endif
     const T* in = static_cast<const T*>(images);
     if constexpr (sizeof(T) == 1) {
         if (u8_half) {

@@ -152,3 +152,18 @@ def test_histogram_matching_random_cases_bit_exact(golden):
         got = hb.transform(x.to(dev), hb.compute_reference_histograms(ref.to(dev))).cpu().numpy()
         want = g[f"c{i}_out"]
         assert got.dtype == want.dtype and np.array_equal(got, want), (i, n, h, w, name)
+
+
+def test_hm_fit_and_transform_under_inference_mode(dev):
+    """the stacked-reference cache read `_version`, which inference tensors do not have -- every transform after a fit
+    under torch.inference_mode() raised.  Fit and transform inside inference mode, twice, and against the call outside it."""
+    from stainx_amd import HistogramMatching
+
+    ref = synth.noise_u8((1, 3, 96, 80), 42).to(dev)
+    src = synth.noise_u8((3, 3, 96, 80), 43).to(dev)
+    want = HistogramMatching(device=dev, backend="torch_hip").fit(ref).transform(src)
+    with torch.inference_mode():
+        hm = HistogramMatching(device=dev, backend="torch_hip").fit(ref)
+        first = hm.transform(src)
+        second = hm.transform(src)
+    assert torch.equal(first.cpu(), want.cpu()) and torch.equal(second.cpu(), want.cpu())
