@@ -177,8 +177,8 @@ int sx_reinhard_transform(const void* images_dev, void* out_dev, int dtype, int6
                           int64_t width, const float* ref_mean_dev, const float* ref_std_dev,
                           void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Batch statistics pooled across ranks: sx_reinhard_sums writes 6 fp64 local sums (sum and sum of squares of
- * LAB-128 per channel) -> all-reduce(SUM) -> sx_reinhard_apply normalises with the global sums over
+/* Batch statistics pooled across ranks: sx_reinhard_sums writes 6 fp64 local sums (sum and sum of squares, per
+ * channel, of the quantities LAB is affine in: f_y, f_x - f_y, f_y - f_z; opaque to the caller) -> all-reduce(SUM) -> sx_reinhard_apply normalises with the global sums over
  * n_total_pixels = pixels per channel over all ranks. */
 int sx_reinhard_sums(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
                      double* sums_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);

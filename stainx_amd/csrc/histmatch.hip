@@ -91,14 +91,21 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const T* __restrict
 // Planar layout, 16-byte packs: a workgroup takes one chunk of ONE channel plane, so a single 256-bin histogram is live
 // and LDS has room for 32 copies of it, copy k in bank k: lane l only ever touches bank l % 32, so the 64 lanes of an
 // atomic instruction never collide on a bank (random grey levels into a single histogram: ~5 of 64 lanes per bank and
-// 13 cycles per instruction measured; this form is bound by the HBM read instead).  Integer adds: bit-exact.
+// 13 cycles per instruction measured).  Integer adds: bit-exact.
+// What bounds it (tools/histbench.hip, 201 MB of uint8, one MI355X): the LDS atomic unit takes one ds_add_u32 per ~6.7 cycles and
+// CU whatever its lanes do (64, 32 or 16 active lanes and fixed conflict-free addresses: 39-40 us) -- 16 instructions per 16-byte
+// pack, 38-39 us for the batch against 31 us for reading it.  Reaching that floor is a matter of waves per CU: 256 threads per
+// 32 KB of copies left 46-49 us; 16 copies reach 39 us on noise and lose on slide background (four lanes of a wave on one
+// address: 50 us); 512 threads SHARING the 32 copies, two packs in flight per thread: 38 us on noise, 36.5 us on background.
 constexpr int kCopies = 32;
 constexpr int kPlaneChunk = 65536;      // elements of one plane per workgroup
+constexpr int kPlaneThreads = 512;
+constexpr int kAhead = 2;               // packs loaded before the first of them is counted
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void histogram_planar_kernel(const T* __restrict__ images, Layout lay, int chunks_per_plane, uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(kPlaneThreads) void histogram_planar_kernel(const T* __restrict__ images, Layout lay, int chunks_per_plane, uint32_t* __restrict__ counts) {
     __shared__ uint32_t hist[kBins][kCopies];
-    for (int i = threadIdx.x; i < kBins * kCopies; i += kThreads) (&hist[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < kBins * kCopies; i += kPlaneThreads) (&hist[0][0])[i] = 0;
     __syncthreads();
     constexpr int V = VecOf<T>::n;
     const int64_t plane = blockIdx.x / chunks_per_plane, chunk = blockIdx.x % chunks_per_plane;
@@ -106,13 +113,22 @@ __global__ __launch_bounds__(kThreads) void histogram_planar_kernel(const T* __r
     const T* src = images + plane * lay.pixels;
     const int64_t begin = chunk * (int64_t)kPlaneChunk, end = min(begin + (int64_t)kPlaneChunk, lay.pixels);
     uint32_t* mine = &hist[0][threadIdx.x & (kCopies - 1)];
-    for (int64_t e = begin + (int64_t)threadIdx.x * V; e < end; e += (int64_t)kThreads * V) {
-        const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(src + e);
+    constexpr int64_t kStride = (int64_t)kPlaneThreads * V;
+    for (int64_t e = begin + (int64_t)threadIdx.x * V; e < end; e += kStride * kAhead) {
+        Pack<T, V> pk[kAhead];
 #pragma unroll
-        for (int i = 0; i < V; ++i) atomicAdd(&mine[grey_level<T>(pk.v[i]) * kCopies], 1u);
+        for (int a = 0; a < kAhead; ++a)
+            if (e + a * kStride < end) pk[a] = *reinterpret_cast<const Pack<T, V>*>(src + e + a * kStride);
+#pragma unroll
+        for (int a = 0; a < kAhead; ++a) {
+            if (e + a * kStride < end) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) atomicAdd(&mine[grey_level<T>(pk[a].v[i]) * kCopies], 1u);
+            }
+        }
     }
     __syncthreads();
-    {   // thread t adds up the copies of bin t, starting at its own bank
+    if (threadIdx.x < kBins) {   // thread t adds up the copies of bin t, starting at its own bank
         const int t = threadIdx.x;
         uint32_t sum = 0;
 #pragma unroll
@@ -321,7 +337,7 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
         if (hipMemsetAsync(tab->counts, 0, sizeof(tab->counts), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
         if (vec && !channels_last) {
             const int chunks_per_plane = (int)((lay.pixels + kPlaneChunk - 1) / kPlaneChunk);
-            hipLaunchKernelGGL((histogram_planar_kernel<T>), dim3((unsigned)(n * 3 * chunks_per_plane)), dim3(kThreads), 0, stream, in, lay, chunks_per_plane, &tab->counts[0][0]);
+            hipLaunchKernelGGL((histogram_planar_kernel<T>), dim3((unsigned)(n * 3 * chunks_per_plane)), dim3(kPlaneThreads), 0, stream, in, lay, chunks_per_plane, &tab->counts[0][0]);
         } else if (vec && channels_last) {
             hipLaunchKernelGGL((histogram_last_kernel<T>), dim3((unsigned)((total + kLastChunk - 1) / kLastChunk)), dim3(kThreads), 0, stream, in, total, &tab->counts[0][0]);
         } else if (vec)
