@@ -70,6 +70,11 @@ SIGNATURES = {
     "sx_hm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "sx_hm_fit": (_int, [_vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
     "sx_hm_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
+    "sx_hm_workspace_init": (_int, [_vp, _sz, _vp]),
+    "sx_hm_workspace_status_offset": (_sz, []),
+    "sx_hm_fit_ready": (_int, [_vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
+    "sx_hm_transform_ready": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
+    "sx_hm_counts_ready": (_int, [_vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None
@@ -144,7 +149,10 @@ class Scratch:
     never freed while this object lives -- a captured HIP graph, or a call still in flight, may hold its address (a superseded
     buffer is retired, not released).  Inside a stream capture the allocation comes from the graph's private pool."""
 
-    def __init__(self):
+    def __init__(self, zeroed: bool = False):
+        # zeroed: buffers are zero-filled when they are made (stream-ordered, once) -- the READY state of the histogram-matching
+        # workspace (include/stainx_hip.h: sx_hm_*_ready); nobody but the library writes to them afterwards
+        self._zeroed = zeroed
         self._bufs: dict[tuple[int, int], torch.Tensor] = {}
         self._retired: list[torch.Tensor] = []
 
@@ -154,6 +162,14 @@ class Scratch:
         if buf is None or buf.numel() < nbytes:
             if buf is not None:
                 self._retired.append(buf)
-            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            make = torch.zeros if self._zeroed else torch.empty
+            buf = make(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             self._bufs[key] = buf
         return buf
+
+    def drop(self, device: torch.device) -> None:
+        """Forget the current stream's buffer (after a failed call its state is unknown): the next get() makes a new one."""
+        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+        buf = self._bufs.pop(key, None)
+        if buf is not None:
+            self._retired.append(buf)

@@ -436,6 +436,20 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         super().__init__(device)
         self.channel_axis = channel_axis
         self.last_workspace: torch.Tensor | None = None
+        # the workspace is zero-filled when it is made and every library call leaves it zeroed again: the sx_hm_*_ready entry
+        # points, which have no clearing launch in front of the histogram pass (include/stainx_hip.h)
+        self._scratch = _native.Scratch(zeroed=True)
+        self._status_offset = int(self._lib.sx_hm_workspace_status_offset())
+
+    def _check_ready_call(self, rc: int, what: str) -> None:
+        if rc != 0:
+            self._scratch.drop(self.device)      # (a failed call may have left counters behind)
+        _native.check(rc, what)
+
+    def workspace_status(self) -> int:
+        """Bit 0: a call found the workspace not in its ready state (synchronises; for tests and diagnosis)."""
+        ws = self.last_workspace
+        return 0 if ws is None else int(ws[self._status_offset:self._status_offset + 4].view(torch.int32).item())
 
     def _channels_last(self, images: torch.Tensor) -> bool:
         return self.channel_axis == -1 or (self.channel_axis == 3 and images.ndim == 4)      # torch_backend.py:182
@@ -457,9 +471,9 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         hists = torch.empty((3, 256), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
-            rc = self._lib.sx_hm_fit(images.data_ptr(), _dtype_code(images), n, h, w, int(last), hists.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     _native.stream_ptr(self.device))
-        _native.check(rc, "sx_hm_fit")
+            rc = self._lib.sx_hm_fit_ready(images.data_ptr(), _dtype_code(images), n, h, w, int(last), hists.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           _native.stream_ptr(self.device))
+        self._check_ready_call(rc, "sx_hm_fit_ready")
         return [hists[c] for c in range(3)]
 
     def _stack_reference(self, reference_histogram, chans: int) -> torch.Tensor:
@@ -511,9 +525,9 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
             return out
         with torch.cuda.device(self.device):
             ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
-            rc = self._lib.sx_hm_transform(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, int(last), ref.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
-        _native.check(rc, "sx_hm_transform")
+            rc = self._lib.sx_hm_transform_ready(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, int(last), ref.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        self._check_ready_call(rc, "sx_hm_transform_ready")
         self.last_workspace = ws
         return out
 
@@ -524,9 +538,9 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         counts = torch.empty((3, 256), dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
             ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
-            rc = self._lib.sx_hm_counts(images.data_ptr(), _dtype_code(images), n, h, w, int(last), counts.data_ptr(), ws.data_ptr(), ws.numel(),
-                                        _native.stream_ptr(self.device))
-        _native.check(rc, "sx_hm_counts")
+            rc = self._lib.sx_hm_counts_ready(images.data_ptr(), _dtype_code(images), n, h, w, int(last), counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              _native.stream_ptr(self.device))
+        self._check_ready_call(rc, "sx_hm_counts_ready")
         return counts
 
     def apply_with_counts(self, images: torch.Tensor, counts: torch.Tensor, n_total_pixels: int, reference_histogram) -> torch.Tensor:

@@ -16,6 +16,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstddef>
 
 namespace sx {
 namespace histmatch {
@@ -25,10 +26,15 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / kWave;
 
 struct alignas(256) Tables {
-    uint32_t counts[3][kBins];      // pooled integer histogram of the source batch
+    uint32_t counted[3][kBins];     // pooled integer histogram of the source batch as the last call counted it (for inspection)
     float lut[3][kBins];            // float LUT (torch_backend.py:276-281)
     uint64_t typed_lut[3][kBins];   // LUT already converted to the output element (low bytes)
     unsigned long long counts64[3][kBins];   // the histogram the LUT is built from (local, or all-reduced over ranks)
+    // The live counters of the histogram pass.  Every entry point that counts also CONSUMES them (the kernel that reads them writes
+    // zeros back), so a workspace that was zero before a call is zero after it: the *_ready entry points rely on that and skip the
+    // hipMemsetAsync launch in front of the histogram pass (5 us of a 115 us call); the plain entry points clear them first.
+    uint32_t counts[3][kBins];
+    uint32_t status;                // bit 0: a *_ready call found counters that do not add up to the pixels it counted (workspace not ready)
 };
 
 struct Layout {
@@ -88,6 +94,194 @@ __global__ __launch_bounds__(kThreads) void histogram_kernel(const T* __restrict
     }
 }
 
+// Channels-last layout, 16-byte packs: the three channels alternate inside a pack, so three histograms are live: 16 copies of
+// each (48 KB); word (channel*256 + bin)*16 + k lies in bank 16*(bin & 1) + k, so
+// the four lanes that share a copy collide only when their bins have the same parity -- two lanes per bank on average where the
+// per-wave histograms of histogram_kernel() put five.
+constexpr int kLastCopies = 16;
+constexpr int kLastChunk = 65536;       // elements (bytes for uint8) per workgroup; a multiple of 3 * V is not needed: the channel follows e % 3
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void histogram_last_kernel(const T* __restrict__ images, int64_t total, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t hist[3][kBins][kLastCopies];
+    for (int i = threadIdx.x; i < 3 * kBins * kLastCopies; i += kThreads) (&hist[0][0][0])[i] = 0;
+    __syncthreads();
+    constexpr int V = VecOf<T>::n;
+    const int64_t begin = (int64_t)blockIdx.x * kLastChunk, end = min(begin + (int64_t)kLastChunk, total);
+    const int copy = threadIdx.x & (kLastCopies - 1);
+    for (int64_t e = begin + (int64_t)threadIdx.x * V; e < end; e += (int64_t)kThreads * V) {
+        const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(images + e);
+        int c = (int)(e % 3);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            atomicAdd(&hist[c][grey_level<T>(pk.v[i])][copy], 1u);
+            c = c == 2 ? 0 : c + 1;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * kBins; i += kThreads) {      // thread t adds up the copies of bin t of each channel, starting at its own bank
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < kLastCopies; ++k) sum += (&hist[0][0][0])[i * kLastCopies + ((threadIdx.x + k) & (kLastCopies - 1))];
+        if (sum) atomicAdd(&counts[i], sum);
+    }
+}
+
+// torch.sum() of 256 contiguous float32 on the CPU (the reference's `counts.sum()` / `ref_hist.float().sum()`,
+// torch_backend.py:141,222): not a plain running sum -- ATen's vectorised reduction keeps four accumulators of eight lanes
+// over blocks of 32 elements, adds the accumulators in order, then the eight lanes in order.  Reproduced as is (verified
+// against torch 2.10 on 300 random histograms, tools/check_torch_sum.py): a sum accumulated any other way differs in the
+// last bit for ~20 % of histograms, which moves LUT entries by 1e-7 and flips a grey level at truncation boundaries.
+template <class At>
+__device__ inline float torch_sum_256(At at) {
+    float acc[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[k][l] = 0.0f;
+#pragma unroll 1      // (unrolled eight times it needs 140 registers: too many beside the histogram pass that also calls it)
+    for (int i = 0; i < kBins / 32; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[k][l] = __fadd_rn(acc[k][l], at(i * 32 + k * 8 + l));
+    float total = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        const float lane = __fadd_rn(__fadd_rn(__fadd_rn(acc[0][l], acc[1][l]), acc[2][l]), acc[3][l]);
+        total = l == 0 ? lane : __fadd_rn(total, lane);
+    }
+    return total;
+}
+
+// fit: normalised histogram  counts / (sum(counts) + 1e-8)  in float32 (torch_backend.py:139-141)
+__global__ void normalise_kernel(Tables* __restrict__ tab, float* __restrict__ hist_out) {
+    const int c = blockIdx.x;
+    __shared__ float total_s;
+    __shared__ float raw[kBins];
+    const uint32_t count = tab->counts[c][threadIdx.x];
+    tab->counts[c][threadIdx.x] = 0;      // consumed
+    tab->counted[c][threadIdx.x] = count;
+    raw[threadIdx.x] = (float)count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        total_s = torch_sum_256([&](int b) { return raw[b]; }) + 1e-8f;
+    }
+    __syncthreads();
+    hist_out[c * kBins + threadIdx.x] = raw[threadIdx.x] / total_s;
+}
+
+template <typename O> __device__ __forceinline__ uint64_t pack_elem(O v) {
+    uint64_t bits = 0;
+    __builtin_memcpy(&bits, &v, sizeof(O));
+    return bits;
+}
+
+__global__ void widen_kernel(Tables* __restrict__ tab, unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * kBins) {
+        const uint32_t count = (&tab->counts[0][0])[i];
+        (&tab->counts[0][0])[i] = 0;      // consumed
+        (&tab->counted[0][0])[i] = count;
+        out[i] = count;
+    }
+}
+
+// One LUT entry: where the source's running sum s of grey level t falls among the reference's running sums.  InT decides the range
+// rules of the output (:288-298).
+template <typename T>
+__device__ __forceinline__ void lut_entry(Tables* __restrict__ tab, int c, int t, float s, const float* ref_cdf) {
+    // searchsorted(right=False): first index with ref_cdf[idx] >= s; clamp to [1,255] (:260-261)
+    int lo = 0, hi = kBins;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ref_cdf[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    const int idx = min(max(lo, 1), kBins - 1);
+    const float q_lo = ref_cdf[idx - 1], q_hi = ref_cdf[idx];
+    const float diff = q_hi - q_lo;
+    const float alpha = diff > 1e-10f ? (s - q_lo) / diff : 0.0f;                    // :272-273
+    float v = (float)(idx - 1) + alpha * ((float)idx - (float)(idx - 1));             // :276
+    if (s <= ref_cdf[0]) v = 0.0f;                                                    // :268, :279
+    if (s >= ref_cdf[kBins - 1]) v = 255.0f;                                          // :269, :280
+    v = fminf(fmaxf(v, 0.0f), 255.0f);                                                // :281
+    tab->lut[c][t] = v;
+    if constexpr (sizeof(T) == 1) {
+        tab->typed_lut[c][t] = pack_elem<uint8_t>((uint8_t)v);                        // stays 0..255, truncated
+    } else {
+        const float unit = fminf(fmaxf(v / 255.0f, 0.0f), 1.0f);                      // :291, :296
+        if constexpr (sizeof(T) == 8) tab->typed_lut[c][t] = pack_elem<double>((double)unit);
+        else tab->typed_lut[c][t] = pack_elem<T>(Elem<T>::store(unit));
+    }
+}
+
+// running sum in double rounded per entry (:236): the order is torch.cumsum's, so one thread per table walks it -- sixteen
+// terms are fetched from LDS at a time (one LDS latency per term made the LUT kernel 11 us; the additions alone are ~1 us)
+__device__ __forceinline__ void running_sum(const float* term, float* cdf) {
+    double run = 0.0;
+#pragma unroll 1
+    for (int b0 = 0; b0 < kBins; b0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = term[b0 + u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            run += (double)v[u];
+            cdf[b0 + u] = (float)run;
+        }
+    }
+}
+
+// One workgroup of 256 threads per channel.
+// (Tried: the LUT inside the histogram launch -- its first workgroup prepares the reference's running sums, the workgroup whose counts
+// arrive last does the rest -- to save this launch and its boundary.  Same bits, and slower: 121 against 114 us per call.  Every one of
+// the 3072 workgroups then waits for its counter adds to be acknowledged and for a ticket from ONE address before it may leave its
+// CU: the histogram launch went from 36 to 57 us, more than this kernel's 8.8 us and the boundary together.)
+template <typename T>
+__global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, const unsigned long long* __restrict__ counts, const bool local, const float* __restrict__ ref_hist, double num_pixels) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    __shared__ float src_cdf[kBins], ref_cdf[kBins];
+    __shared__ float src_term[kBins], ref_term[kBins];
+    __shared__ float ref_denom_s;
+    __shared__ float ref_raw[kBins];
+    // the divisions run one per thread; only the two running sums are sequential (that order is torch.cumsum's)
+    ref_raw[t] = ref_hist[c * kBins + t];      // (one load per thread: the summing thread reading global memory itself paid eight round trips)
+    __syncthreads();
+    if (t == 64) {
+        // reference: h / (sum(h) + 1e-8) (:222-223)
+        ref_denom_s = torch_sum_256([&](int b) { return ref_raw[b]; }) + 1e-8f;
+    }
+    // source: counts / float(num_pixels + 1e-8) (:235)
+    // (the local histogram is read as it was counted; counts pooled over ranks arrive widened to 64 bits)
+    unsigned long long count;
+    if (local) {
+        const uint32_t mine = tab->counts[c][t];
+        tab->counts[c][t] = 0;      // consumed: the next call's histogram pass starts from zero
+        tab->counted[c][t] = mine;
+        count = mine;
+        // the counters of a call add up to its pixels -- unless the workspace was not ready (see Tables)
+        const double wave_total = wave_sum((double)mine);      // (integers below 2^53: exact)
+        __shared__ double parts[kBins / kWave];
+        if (lane_id() == 0) parts[t / kWave] = wave_total;
+        __syncthreads();
+        if (t == 0) {
+            double total = 0.0;
+            for (int w = 0; w < kBins / kWave; ++w) total += parts[w];
+            if (total != num_pixels) atomicOr(&tab->status, 1u);
+        }
+    } else {
+        count = counts[c * kBins + t];
+    }
+    src_term[t] = (float)count / (float)(num_pixels + 1e-8);
+    __syncthreads();
+    ref_term[t] = ref_raw[t] / ref_denom_s;
+    __syncthreads();
+    if (t == 0) running_sum(src_term, src_cdf);
+    else if (t == 64) running_sum(ref_term, ref_cdf);
+    __syncthreads();
+    lut_entry<T>(tab, c, t, src_cdf[t], ref_cdf);
+}
+
 // Planar layout, 16-byte packs: a workgroup takes one chunk of ONE channel plane, so a single 256-bin histogram is live
 // and LDS has room for 32 copies of it, copy k in bank k: lane l only ever touches bank l % 32, so the 64 lanes of an
 // atomic instruction never collide on a bank (random grey levels into a single histogram: ~5 of 64 lanes per bank and
@@ -137,155 +331,6 @@ __global__ __launch_bounds__(kPlaneThreads) void histogram_planar_kernel(const T
     }
 }
 
-// Channels-last layout, 16-byte packs: the three channels alternate inside a pack, so three histograms are live: 16 copies of
-// each (48 KB); word (channel*256 + bin)*16 + k lies in bank 16*(bin & 1) + k, so
-// the four lanes that share a copy collide only when their bins have the same parity -- two lanes per bank on average where the
-// per-wave histograms of histogram_kernel() put five.
-constexpr int kLastCopies = 16;
-constexpr int kLastChunk = 65536;       // elements (bytes for uint8) per workgroup; a multiple of 3 * V is not needed: the channel follows e % 3
-
-template <typename T>
-__global__ __launch_bounds__(kThreads) void histogram_last_kernel(const T* __restrict__ images, int64_t total, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t hist[3][kBins][kLastCopies];
-    for (int i = threadIdx.x; i < 3 * kBins * kLastCopies; i += kThreads) (&hist[0][0][0])[i] = 0;
-    __syncthreads();
-    constexpr int V = VecOf<T>::n;
-    const int64_t begin = (int64_t)blockIdx.x * kLastChunk, end = min(begin + (int64_t)kLastChunk, total);
-    const int copy = threadIdx.x & (kLastCopies - 1);
-    for (int64_t e = begin + (int64_t)threadIdx.x * V; e < end; e += (int64_t)kThreads * V) {
-        const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(images + e);
-        int c = (int)(e % 3);
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            atomicAdd(&hist[c][grey_level<T>(pk.v[i])][copy], 1u);
-            c = c == 2 ? 0 : c + 1;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 3 * kBins; i += kThreads) {      // thread t adds up the copies of bin t of each channel, starting at its own bank
-        uint32_t sum = 0;
-#pragma unroll
-        for (int k = 0; k < kLastCopies; ++k) sum += (&hist[0][0][0])[i * kLastCopies + ((threadIdx.x + k) & (kLastCopies - 1))];
-        if (sum) atomicAdd(&counts[i], sum);
-    }
-}
-
-// torch.sum() of 256 contiguous float32 on the CPU (the reference's `counts.sum()` / `ref_hist.float().sum()`,
-// torch_backend.py:141,222): not a plain running sum -- ATen's vectorised reduction keeps four accumulators of eight lanes
-// over blocks of 32 elements, adds the accumulators in order, then the eight lanes in order.  Reproduced as is (verified
-// against torch 2.10 on 300 random histograms, tools/check_torch_sum.py): a sum accumulated any other way differs in the
-// last bit for ~20 % of histograms, which moves LUT entries by 1e-7 and flips a grey level at truncation boundaries.
-template <class At>
-__device__ inline float torch_sum_256(At at) {
-    float acc[4][8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int l = 0; l < 8; ++l) acc[k][l] = 0.0f;
-    for (int i = 0; i < kBins / 32; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int l = 0; l < 8; ++l) acc[k][l] = __fadd_rn(acc[k][l], at(i * 32 + k * 8 + l));
-    float total = 0.0f;
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
-        const float lane = __fadd_rn(__fadd_rn(__fadd_rn(acc[0][l], acc[1][l]), acc[2][l]), acc[3][l]);
-        total = l == 0 ? lane : __fadd_rn(total, lane);
-    }
-    return total;
-}
-
-// fit: normalised histogram  counts / (sum(counts) + 1e-8)  in float32 (torch_backend.py:139-141)
-__global__ void normalise_kernel(const uint32_t* __restrict__ counts, float* __restrict__ hist_out) {
-    const int c = blockIdx.x;
-    __shared__ float total_s;
-    __shared__ float raw[kBins];
-    raw[threadIdx.x] = (float)counts[c * kBins + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        total_s = torch_sum_256([&](int b) { return raw[b]; }) + 1e-8f;
-    }
-    __syncthreads();
-    hist_out[c * kBins + threadIdx.x] = raw[threadIdx.x] / total_s;
-}
-
-template <typename O> __device__ __forceinline__ uint64_t pack_elem(O v) {
-    uint64_t bits = 0;
-    __builtin_memcpy(&bits, &v, sizeof(O));
-    return bits;
-}
-
-__global__ void widen_kernel(const uint32_t* __restrict__ counts, unsigned long long* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * kBins) out[i] = counts[i];
-}
-
-// One workgroup of 256 threads per channel.  InT decides the range rules of the output (:288-298).
-template <typename T>
-__global__ __launch_bounds__(kBins) void lut_kernel(Tables* __restrict__ tab, const unsigned long long* __restrict__ counts, const uint32_t* __restrict__ counts32, const float* __restrict__ ref_hist, double num_pixels) {
-    const int c = blockIdx.x, t = threadIdx.x;
-    __shared__ float src_cdf[kBins], ref_cdf[kBins];
-    __shared__ float src_term[kBins], ref_term[kBins];
-    __shared__ float ref_denom_s;
-    __shared__ float ref_raw[kBins];
-    // the divisions run one per thread; only the two running sums are sequential (that order is torch.cumsum's)
-    ref_raw[t] = ref_hist[c * kBins + t];      // (one load per thread: the summing thread reading global memory itself paid eight round trips)
-    __syncthreads();
-    if (t == 64) {
-        // reference: h / (sum(h) + 1e-8) (:222-223)
-        ref_denom_s = torch_sum_256([&](int b) { return ref_raw[b]; }) + 1e-8f;
-    }
-    // source: counts / float(num_pixels + 1e-8) (:235)
-    // (the local histogram is read as it was counted; counts pooled over ranks arrive widened to 64 bits)
-    const unsigned long long count = counts32 ? (unsigned long long)counts32[c * kBins + t] : counts[c * kBins + t];
-    src_term[t] = (float)count / (float)(num_pixels + 1e-8);
-    __syncthreads();
-    ref_term[t] = ref_raw[t] / ref_denom_s;
-    __syncthreads();
-    // running sum in double rounded per entry (:236): the order is torch.cumsum's, so one thread per table walks it -- sixteen
-    // terms are fetched from LDS at a time (one LDS latency per term made this kernel 11 us; the additions alone are ~1 us)
-    auto running_sum = [](const float* term, float* cdf) {
-        double run = 0.0;
-        for (int b0 = 0; b0 < kBins; b0 += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = term[b0 + u];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                run += (double)v[u];
-                cdf[b0 + u] = (float)run;
-            }
-        }
-    };
-    if (t == 0) running_sum(src_term, src_cdf);
-    else if (t == 64) running_sum(ref_term, ref_cdf);
-    __syncthreads();
-    const float s = src_cdf[t];
-    // searchsorted(right=False): first index with ref_cdf[idx] >= s; clamp to [1,255] (:260-261)
-    int lo = 0, hi = kBins;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (ref_cdf[mid] < s) lo = mid + 1; else hi = mid;
-    }
-    const int idx = min(max(lo, 1), kBins - 1);
-    const float q_lo = ref_cdf[idx - 1], q_hi = ref_cdf[idx];
-    const float diff = q_hi - q_lo;
-    const float alpha = diff > 1e-10f ? (s - q_lo) / diff : 0.0f;                    // :272-273
-    float v = (float)(idx - 1) + alpha * ((float)idx - (float)(idx - 1));             // :276
-    if (s <= ref_cdf[0]) v = 0.0f;                                                    // :268, :279
-    if (s >= ref_cdf[kBins - 1]) v = 255.0f;                                          // :269, :280
-    v = fminf(fmaxf(v, 0.0f), 255.0f);                                                // :281
-    tab->lut[c][t] = v;
-    if constexpr (sizeof(T) == 1) {
-        tab->typed_lut[c][t] = pack_elem<uint8_t>((uint8_t)v);                        // stays 0..255, truncated
-    } else {
-        const float unit = fminf(fmaxf(v / 255.0f, 0.0f), 1.0f);                      // :291, :296
-        if constexpr (sizeof(T) == 8) tab->typed_lut[c][t] = pack_elem<double>((double)unit);
-        else tab->typed_lut[c][t] = pack_elem<T>(Elem<T>::store(unit));
-    }
-}
-
 template <typename T, bool kVec>
 __global__ __launch_bounds__(kThreads) void apply_kernel(const T* __restrict__ images, T* __restrict__ out, Layout lay, const Tables* __restrict__ tab) {
     __shared__ T lut[3][kBins];
@@ -319,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const T* __restrict__ i
 static size_t workspace_bytes() { return sizeof(Tables); }
 
 template <typename T>
-static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, unsigned long long* counts_out, const unsigned long long* counts_in, double n_total, void* ws, hipStream_t stream) {
+static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, unsigned long long* counts_out, const unsigned long long* counts_in, double n_total, void* ws, hipStream_t stream, bool ready) {
     Layout lay{n, h * w, channels_last};
     Tables* tab = static_cast<Tables*>(ws);
     const T* in = static_cast<const T*>(images);
@@ -330,11 +375,9 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
                      (channels_last ? (total % V == 0) : (lay.pixels % V == 0));
     const int64_t per_block = (int64_t)kThreads * (vec ? V : 1) * 4;
     const unsigned grid = (unsigned)std::min<int64_t>((total + per_block - 1) / per_block, 256 * 8);
-    const unsigned long long* lut_counts = counts_in;
-    const uint32_t* lut_counts32 = nullptr;
     double lut_pixels = n_total;
     if (!counts_in) {
-        if (hipMemsetAsync(tab->counts, 0, sizeof(tab->counts), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
+        if (!ready && hipMemsetAsync(tab->counts, 0, sizeof(tab->counts) + sizeof(tab->status), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
         if (vec && !channels_last) {
             const int chunks_per_plane = (int)((lay.pixels + kPlaneChunk - 1) / kPlaneChunk);
             hipLaunchKernelGGL((histogram_planar_kernel<T>), dim3((unsigned)(n * 3 * chunks_per_plane)), dim3(kPlaneThreads), 0, stream, in, lay, chunks_per_plane, &tab->counts[0][0]);
@@ -345,17 +388,16 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
         else
             hipLaunchKernelGGL((histogram_kernel<T, false>), dim3(grid), dim3(kThreads), 0, stream, in, lay, &tab->counts[0][0]);
         if (hist_out) {
-            hipLaunchKernelGGL(normalise_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], hist_out);
+            hipLaunchKernelGGL(normalise_kernel, dim3(3), dim3(kBins), 0, stream, tab, hist_out);
             return check_launch("histogram fit");
         }
         if (counts_out) {
-            hipLaunchKernelGGL(widen_kernel, dim3(3), dim3(kBins), 0, stream, &tab->counts[0][0], counts_out);
+            hipLaunchKernelGGL(widen_kernel, dim3(3), dim3(kBins), 0, stream, tab, counts_out);
             return check_launch("histogram counts");
         }
-        lut_counts32 = &tab->counts[0][0];
         lut_pixels = (double)(n * h * w);
     }
-    hipLaunchKernelGGL((lut_kernel<T>), dim3(3), dim3(kBins), 0, stream, tab, lut_counts, lut_counts32, ref_hist, lut_pixels);
+    hipLaunchKernelGGL((lut_kernel<T>), dim3(3), dim3(kBins), 0, stream, tab, counts_in, counts_in == nullptr, ref_hist, lut_pixels);
     if (vec)
         hipLaunchKernelGGL((apply_kernel<T, true>), dim3(grid), dim3(kThreads), 0, stream, in, static_cast<T*>(out), lay, tab);
     else
@@ -363,18 +405,18 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
     return check_launch("histogram transform");
 }
 
-static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, unsigned long long* counts_out, const unsigned long long* counts_in, double n_total, void* ws, size_t ws_bytes, void* stream_ptr) {
+static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, unsigned long long* counts_out, const unsigned long long* counts_in, double n_total, void* ws, size_t ws_bytes, void* stream_ptr, bool ready = false) {
     if (!images) return fail(SX_ERR_BAD_ARG, "images pointer is null");
     if (n <= 0 || h <= 0 || w <= 0) return fail(SX_ERR_BAD_ARG, "images must have positive sizes, got N=%lld H=%lld W=%lld", (long long)n, (long long)h, (long long)w);
     if (!ws || ws_bytes < workspace_bytes()) return fail(SX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", workspace_bytes(), ws_bytes);
     if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(SX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
-        case SX_U8: return run<uint8_t>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
-        case SX_F16: return run<__half>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
-        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
-        case SX_F32: return run<float>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
-        case SX_F64: return run<double>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream);
+        case SX_U8: return run<uint8_t>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream, ready);
+        case SX_F16: return run<__half>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream, ready);
+        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream, ready);
+        case SX_F32: return run<float>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream, ready);
+        case SX_F64: return run<double>(images, out, n, h, w, channels_last, ref_hist, hist_out, counts_out, counts_in, n_total, ws, stream, ready);
         default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
     }
 }
@@ -397,6 +439,32 @@ extern "C" int sx_hm_fit(const void* images, int dtype, int64_t n, int64_t h, in
 extern "C" int sx_hm_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, void* ws, size_t ws_bytes, void* stream) {
     if (!out || !ref_hist) return fail(SX_ERR_BAD_ARG, "out / ref_hist pointer is null");
     return histmatch::dispatch(images, out, dtype, n, h, w, channels_last, ref_hist, nullptr, nullptr, nullptr, 0.0, ws, ws_bytes, stream);
+}
+
+// The same calls on a workspace in the READY state -- zero-filled by sx_hm_workspace_init() or left behind by any completed call of
+// this section on it: no clearing launch in front of the histogram pass.  A workspace that was not ready is noticed (the counters do
+// not add up to the pixels counted) and reported by sx_hm_workspace_status(); the result of that call is not to be used.
+extern "C" int sx_hm_workspace_init(void* ws, size_t ws_bytes, void* stream) {
+    if (!ws || ws_bytes < histmatch::workspace_bytes()) return fail(SX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", histmatch::workspace_bytes(), ws_bytes);
+    if (hipMemsetAsync(ws, 0, histmatch::workspace_bytes(), static_cast<hipStream_t>(stream)) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
+    return SX_OK;
+}
+
+extern "C" size_t sx_hm_workspace_status_offset(void) { return offsetof(histmatch::Tables, status); }
+
+extern "C" int sx_hm_fit_ready(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, float* hist_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!hist_out) return fail(SX_ERR_BAD_ARG, "hist_out pointer is null");
+    return histmatch::dispatch(images, nullptr, dtype, n, h, w, channels_last, nullptr, hist_out, nullptr, nullptr, 0.0, ws, ws_bytes, stream, true);
+}
+
+extern "C" int sx_hm_transform_ready(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, void* ws, size_t ws_bytes, void* stream) {
+    if (!out || !ref_hist) return fail(SX_ERR_BAD_ARG, "out / ref_hist pointer is null");
+    return histmatch::dispatch(images, out, dtype, n, h, w, channels_last, ref_hist, nullptr, nullptr, nullptr, 0.0, ws, ws_bytes, stream, true);
+}
+
+extern "C" int sx_hm_counts_ready(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, unsigned long long* counts_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!counts_out) return fail(SX_ERR_BAD_ARG, "counts_out pointer is null");
+    return histmatch::dispatch(images, nullptr, dtype, n, h, w, channels_last, nullptr, nullptr, counts_out, nullptr, 0.0, ws, ws_bytes, stream, true);
 }
 
 // Source histogram pooled ACROSS RANKS: local integer counts out (3 x 256 u64), all-reduce on the host side, apply with the global counts.

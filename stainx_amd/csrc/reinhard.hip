@@ -127,13 +127,15 @@ __device__ __forceinline__ void f_to_rgb(float fx, float fy, float fz, float rgb
     }
 }
 
+constexpr int kTileCounterStride = 32;      // uint32 words between two tiles' arrival counters (128 bytes: a line each)
+
 struct Geometry {
     int64_t n_tiles, pixels;
     int blocks_per_tile, chunk;
 };
 
 template <typename T, int V>
-__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, State* __restrict__ st, double* __restrict__ partial, float* __restrict__ mean_out, float* __restrict__ std_out, double* __restrict__ sums_out) {
+__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, State* __restrict__ st, double* __restrict__ partial, unsigned int* __restrict__ tile_arrivals, float* __restrict__ mean_out, float* __restrict__ std_out, double* __restrict__ sums_out) {
     const int64_t tile = blockIdx.x / g.blocks_per_tile;
     const int chunk_id = blockIdx.x % g.blocks_per_tile;
     const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
@@ -182,8 +184,15 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int ticket = __hip_atomic_fetch_add(&st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = ticket == gridDim.x - 1;
+        // two levels of arrival counters: a tile's work items on the tile's own word (its own 128-byte line), the tile's last arrival
+        // on the call's word.  The work items all finish within a few microseconds of each other and one address takes ~90 atomic
+        // operations per microsecond: 2048 tickets from ONE word kept the last workgroups waiting for theirs
+        unsigned int* mine = tile_arrivals + tile * kTileCounterStride;
+        last = false;
+        if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.blocks_per_tile - 1) {
+            __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call on this workspace
+            last = __hip_atomic_fetch_add(&st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.n_tiles - 1;
+        }
     }
     __syncthreads();
     if (!last) return;
@@ -282,9 +291,14 @@ static int blocks_for(int64_t pixels) {
     const int64_t chunk = (int64_t)kStreamThreads * 4 * kIters;
     return (int)((pixels + chunk - 1) / chunk);
 }
-static size_t workspace_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(State), 256) + align_up(sizeof(double) * kSums * (size_t)blocks_for(pixels) * (size_t)n, 256); }
+static size_t partial_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(double) * kSums * (size_t)blocks_for(pixels) * (size_t)n, 256); }
+static size_t workspace_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(State), 256) + partial_bytes(n, pixels) + align_up(sizeof(unsigned int) * kTileCounterStride * (size_t)n, 256); }
 
-__global__ void init_state_kernel(State* st) { st->arrivals = 0; }
+__global__ void init_state_kernel(State* st, unsigned int* tile_arrivals, int64_t n_tiles) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i == 0) st->arrivals = 0;
+    if (i < n_tiles) tile_arrivals[i * kTileCounterStride] = 0;
+}
 
 // mean / unbiased std of LAB from (possibly all-reduced) sums of e over n pixels per channel
 __global__ void finalize_kernel(const double* __restrict__ sums, double n, State* __restrict__ st) {
@@ -301,17 +315,18 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, c
     Geometry g{n, h * w, blocks_for(h * w), kStreamThreads * 4 * kIters};
     State* st = static_cast<State*>(ws);
     double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + align_up(sizeof(State), 256));
+    unsigned int* tile_arrivals = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(partial) + partial_bytes(n, h * w));
     const bool vec = (g.pixels % 4 == 0) && (reinterpret_cast<uintptr_t>(images) % (sizeof(T) * 4) == 0) && (!out || reinterpret_cast<uintptr_t>(out) % (sizeof(T) * 4) == 0);
     const unsigned grid = (unsigned)(n * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
     if (sums_in) {            // statistics come from outside (all-reduced over ranks)
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, sums_in, n_total, st);
     } else {
-        hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, st);
+        hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, tile_arrivals, n);
         if (vec)
-            hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, mean_out, std_out, sums_out);
+            hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, tile_arrivals, mean_out, std_out, sums_out);
         else
-            hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, mean_out, std_out, sums_out);
+            hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, tile_arrivals, mean_out, std_out, sums_out);
     }
     if (out) {
         if (vec)

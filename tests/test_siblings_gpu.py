@@ -167,3 +167,51 @@ def test_hm_fit_and_transform_under_inference_mode(dev):
         first = hm.transform(src)
         second = hm.transform(src)
     assert torch.equal(first.cpu(), want.cpu()) and torch.equal(second.cpu(), want.cpu())
+
+
+def test_histogram_matching_ready_workspace_calls(dev):
+    """include/stainx_hip.h, sx_hm_*_ready: the calls without the clearing launch.  Through the C ABI: the plain call accepts a
+    workspace full of garbage and leaves it ready; the ready calls give the same bits on a ready workspace, one after the other
+    (each leaves it ready: transform, fit, counts); a workspace that was NOT ready is noticed and reported."""
+    from stainx_amd import _native
+    from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
+
+    lib = _native.require()
+    be = HistogramMatchingHIP(dev)
+    src = synth.noise_u8((3, 3, 200, 328), 7).to(dev)
+    ref = torch.stack(be.compute_reference_histograms(synth.noise_u8((1, 3, 200, 328), 8).to(dev))).contiguous()
+    want = torch.from_numpy(so.hm_transform(src.cpu().numpy(), [r.cpu().numpy() for r in ref])).to(dev)
+    n, _, h, w = src.shape
+    u8 = _native.DTYPE_CODES[torch.uint8]
+    stream = _native.stream_ptr(dev)
+    ws = torch.full((int(lib.sx_hm_workspace_bytes(n, h, w)),), 0xA5, dtype=torch.uint8, device=dev)
+    off = int(lib.sx_hm_workspace_status_offset())
+
+    def status():
+        return int(ws[off:off + 4].view(torch.int32).item())
+
+    def run(fn):
+        out = torch.empty_like(src)
+        assert fn(src.data_ptr(), out.data_ptr(), u8, n, h, w, 0, ref.data_ptr(), ws.data_ptr(), ws.numel(), stream) == 0
+        return out
+
+    assert torch.equal(run(lib.sx_hm_transform), want) and status() == 0          # garbage in: the plain call clears what it needs
+    for _ in range(3):
+        assert torch.equal(run(lib.sx_hm_transform_ready), want) and status() == 0
+    hists = torch.empty((3, 256), dtype=torch.float32, device=dev)
+    assert lib.sx_hm_fit_ready(src.data_ptr(), u8, n, h, w, 0, hists.data_ptr(), ws.data_ptr(), ws.numel(), stream) == 0
+    counts = torch.empty((3, 256), dtype=torch.int64, device=dev)
+    assert lib.sx_hm_counts_ready(src.data_ptr(), u8, n, h, w, 0, counts.data_ptr(), ws.data_ptr(), ws.numel(), stream) == 0
+    assert int(counts.sum()) == src.numel()
+    assert torch.equal(hists, torch.stack(be.compute_reference_histograms(src)))
+    assert torch.equal(run(lib.sx_hm_transform_ready), want) and status() == 0
+    ws.fill_(0x01)                                                                   # somebody else wrote here
+    run(lib.sx_hm_transform_ready)
+    assert status() & 1
+    assert lib.sx_hm_workspace_init(ws.data_ptr(), ws.numel(), stream) == 0
+    assert torch.equal(run(lib.sx_hm_transform_ready), want) and status() == 0
+    # the backend's own workspaces are zero-filled when they are made, and it only uses the ready calls
+    for _ in range(3):
+        assert torch.equal(be.transform(src, list(ref)), want)
+    assert be.workspace_status() == 0
+    assert int(be.tables()["counts"].sum()) == src.numel()
