@@ -167,7 +167,11 @@ struct Workspace {
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int blocks_per_tile_for(int64_t pixels) { return (int)((pixels + kChunk - 1) / kChunk); }
+// set_chunk(): which tiles may take one work item more than pixels / kChunk -- those whose two-pass form keeps its candidates in dense
+// records (fused_size() below: the per-wave candidate segments of the other tiles are sized per work item and stay as they were)
+static bool even_items_size(int64_t pixels) { return pixels >= 16384 && pixels <= 262144 && pixels % 4 == 0; }
+// (an upper bound: what the workspace is sized for; the geometry's blocks_per_tile is set_chunk()'s)
+static int blocks_per_tile_for(int64_t pixels) { return (int)((pixels + kChunk - 1) / kChunk) + (even_items_size(pixels) ? 1 : 0); }
 
 // Candidate capacity per slot of a group of `count` pixels: brackets hold ~2-3 % of the pixels.
 static uint32_t cap_for(int64_t count) {
@@ -2585,20 +2589,40 @@ static bool aligned_for(const void* p, size_t bytes) { return (reinterpret_cast<
 // The tile split evenly over its work items (a 224x224 tile is 3 x 16384 + 1024 pixels otherwise: a quarter of the
 // workgroups nearly idle); a function of the tile size and the element type's pack only, so a tile's partial sums are
 // grouped the same way whatever batch -- or entry point -- it arrives through.
-static void set_chunk(Geometry& g) {
+// One work item MORE than the tile needs at 16384 pixels each, where that evens the items out: every work item of a streaming pass is
+// resident at once (1024 of them on 256 CUs for the batches that matter), workgroup b lands on XCD b % 8, and a short last item per
+// tile therefore leaves whole XCDs with short items only while the others set the kernel's time.  224 x 224 bf16: 3 x 14336 + 7168
+// pixels -> 4 x 10240 + 9216 (57344 -> 51200 pixel-times per CU and sweep); 448 x 448: 13 items with a quarter-sized last one ->
+// 14 x 14336.  Taken when it saves more than 3 %, on the tile sizes of even_items_size().
+static void set_chunk(Geometry& g, bool may_add_item) {
     const int64_t unit = (int64_t)kStreamThreads * (g.vec ? g.vec_width : 1);
-    const int64_t even = (g.pixels + g.blocks_per_tile - 1) / g.blocks_per_tile;
-    g.chunk = (int)std::min<int64_t>(kChunk, (even + unit - 1) / unit * unit);
+    const int b0 = (int)((g.pixels + kChunk - 1) / kChunk);
+    int best_b = b0;
+    int64_t best_chunk = 0, best_cost = 0;
+    for (int b = b0; b <= b0 + (may_add_item && even_items_size(g.pixels) ? 1 : 0); ++b) {
+        const int64_t even = (g.pixels + b - 1) / b;
+        const int64_t chunk = std::min<int64_t>(kChunk, (even + unit - 1) / unit * unit);
+        if ((int64_t)(b - 1) * chunk >= g.pixels) continue;      // (the last item would be empty)
+        const int64_t cost = chunk * b;
+        if (best_chunk == 0 || cost * 100 < best_cost * 97) {
+            best_b = b;
+            best_chunk = chunk;
+            best_cost = cost;
+        }
+    }
+    g.blocks_per_tile = best_b;
+    g.chunk = (int)best_chunk;
 }
 
-static void set_sampling(Geometry& g) {
+// (may_add_item: set_chunk(); only the transform takes it -- the fused fit and the staged fits stay bit for bit the same)
+static void set_sampling(Geometry& g, bool may_add_item = false) {
     const int64_t count = g.pooled ? g.n_tiles * g.pixels : g.pixels;
     int64_t stride = 1;                                   // smallest power of two with ceil(count/stride) <= kSample
     while ((count + stride - 1) / stride > kSample) stride *= 2;
     g.sample_stride = (int)stride;
     g.sample_count = (int)std::min<int64_t>(kSample, (count + stride - 1) / stride);
     g.spread = (g.pooled && g.n_tiles > 1) ? 1 : 0;
-    set_chunk(g);
+    set_chunk(g, may_add_item);
     g.cap = cap_for(g.spread ? g.pixels : count);
 }
 
@@ -2706,7 +2730,7 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
     const bool vec = (g.pixels % W == 0) && aligned_for(images, 16) && aligned_for(out, out_elem * W);
     g.vec = vec ? 1 : 0;
     g.vec_width = W;
-    set_sampling(g);
+    set_sampling(g, true);
     if (g.fused && !(vec && !g.interleaved && !u8_half && std::is_same<T, float>::value)) {      // (unaligned pointers: the four-pass form serves them; its workspace is a prefix of the fused one)
         g.fused = 0;
         g.two_pass = 0;
@@ -2733,7 +2757,7 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
         g.fused_cap = fused_cap_for(g.pixels);
         g.fused_items = (int)(g.n_tiles * g.blocks_per_tile);
         g.cap2 = cap2_for(g.pixels);
-        g.n_seg = two_pass_segments(g.pixels);
+        g.n_seg = even_items_size(g.pixels) ? g.blocks_per_tile * (kStreamThreads / kWave) : two_pass_segments(g.pixels);      // (dense records there: no segments; the count of pass-A waves per tile all the same)
         g.seg_cap = seg_cap_for(g.pixels);
         g.over_cap = over_cap_for(g.pixels);
         const int64_t n_sectors = g.pixels / 16;
@@ -2943,7 +2967,7 @@ static int pfit_pass_typed(const void* images, const Geometry& g0, const Workspa
     const bool vec = (g.pixels % W == 0) && aligned_for(images, 16);
     g.vec = vec ? 1 : 0;
     g.vec_width = W;
-    set_chunk(g);
+    set_chunk(g, false);      // (the staged fit's other steps take the work items per tile from make_geometry())
     const unsigned grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
     if (stage < 0) {      // stats
@@ -3139,6 +3163,7 @@ extern "C" int sx_macenko_dfit_result(const void* state, float* he_out, float* m
 static Geometry pfit_geometry(int64_t n, int64_t h, int64_t w, long long n_all, int sample_count) {
     Geometry g = make_geometry(n, h * w, 1);
     set_sampling(g);                 // local sample stride; cap per tile
+    set_chunk(g, false);             // (the same work items per tile in every step of the staged fit: pfit_pass_typed() rounds the chunk for its packs)
     g.spread = 1;                    // also for a single local tile: the group spans other ranks
     g.cap = cap_for(g.pixels);
     g.distributed = 1;

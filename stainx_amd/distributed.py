@@ -178,7 +178,7 @@ def macenko_fit_pooled(local_images: torch.Tensor, *, group=None, steps: Any | N
     return he, max_c
 
 
-def _macenko_fit_pooled(local_images, group, steps, method: str, defer_status: bool):
+def _macenko_fit_pooled(local_images, group, steps, method: str, defer_status: bool, _retried: bool = False):
     if method not in ("brackets", "radix"):
         raise ValueError(f"method must be 'brackets' or 'radix', got {method!r}")
     if method == "brackets" and hasattr(steps, "pfit_stats"):
@@ -200,9 +200,10 @@ def _macenko_fit_pooled(local_images, group, steps, method: str, defer_status: b
         code = int(status.item())
         if code == 0:
             return he, max_c, None
-        if code & 2:      # the cached tile counts were stale: once more with fresh ones (still the bracket form)
+        if code & 2 and not _retried:      # the cached tile counts were stale: once more with fresh ones (still the bracket form)
             _TILE_COUNTS.clear()
-            return _macenko_fit_pooled(local_images, group, steps, method, defer_status)
+            return _macenko_fit_pooled(local_images, group, steps, method, defer_status, _retried=True)
+        # (anything else -- a bracket that missed, or a stale flag that survives fresh counts -- goes on to the radix rounds below)
     else:
         # (both methods: a rank without tiles must fail on EVERY rank here, not leave the others in the next collective)
         tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
