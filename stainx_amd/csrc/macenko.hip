@@ -171,7 +171,11 @@ __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a -
 // records (fused_size() below: the per-wave candidate segments of the other tiles are sized per work item and stay as they were)
 static bool even_items_size(int64_t pixels) { return pixels >= 16384 && pixels <= 262144 && pixels % 4 == 0; }
 // (an upper bound: what the workspace is sized for; the geometry's blocks_per_tile is set_chunk()'s)
+#ifdef SX_STAMPS
+static int blocks_per_tile_for(int64_t pixels) { return (int)((pixels + kChunk - 1) / kChunk) + (even_items_size(pixels) ? 8 : 0); }
+#else
 static int blocks_per_tile_for(int64_t pixels) { return (int)((pixels + kChunk - 1) / kChunk) + (even_items_size(pixels) ? 1 : 0); }
+#endif
 
 // Candidate capacity per slot of a group of `count` pixels: brackets hold ~2-3 % of the pixels.
 static uint32_t cap_for(int64_t count) {
@@ -2610,6 +2614,16 @@ static void set_chunk(Geometry& g, bool may_add_item) {
             best_cost = cost;
         }
     }
+#ifdef SX_STAMPS      // diagnostic builds: work items per tile from the environment
+    if (const char* e = std::getenv("SX_ITEMS")) {
+        const int b = std::atoi(e);
+        const int64_t chunk = std::min<int64_t>(kChunk, ((g.pixels + b - 1) / b + unit - 1) / unit * unit);
+        if (may_add_item && b >= b0 && b <= blocks_per_tile_for(g.pixels) && (int64_t)(b - 1) * chunk < g.pixels) {
+            best_b = b;
+            best_chunk = chunk;
+        }
+    }
+#endif
     g.blocks_per_tile = best_b;
     g.chunk = (int)best_chunk;
 }

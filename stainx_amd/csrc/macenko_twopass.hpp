@@ -841,6 +841,9 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
 // uses, see write_records_fused) instead of a segment per wave: no dirty candidate lines for the kernel boundary to write back
 // (the gap between this launch and the stage was 4.7 us with 25 MB of them), one load per candidate in the stage instead of
 // three, and a third of the workspace.  Tiles up to 512 x 512; larger ones keep the segments.
+// (Occupancy is not what holds this kernel back: built for five waves per SIMD -- 93 registers, a 448-record queue, 29 KB of LDS --
+// and run on 20 work items per 512 x 512 tile, all 1280 resident, the call takes 156.9 us against 156.6 us at four waves and 16
+// items; tools/ab_items.py on a debug build.)
 template <typename T, int V, bool kInter = false, bool kDense = false>
 __global__ __launch_bounds__(kStreamThreads) void pass_a_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ PassAScratch<kStreamThreads> sh;
