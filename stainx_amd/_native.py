@@ -67,6 +67,9 @@ SIGNATURES = {
     "sx_hm_apply": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _int, _vp, _c.c_double, _vp, _vp, _sz, _vp]),
     "sx_reinhard_fit": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sx_reinhard_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "sx_reinhard_workspace_init": (_int, [_vp, _sz, _vp]),
+    "sx_reinhard_workspace_status_offset": (_sz, []),
+    "sx_reinhard_transform_ready": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sx_hm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "sx_hm_fit": (_int, [_vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),
     "sx_hm_transform": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),

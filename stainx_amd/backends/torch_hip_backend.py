@@ -363,6 +363,25 @@ class ReinhardHIP(TorchHIPBackendBase):
         if images.dim() != 4 or images.shape[1] != 3:
             raise ValueError(f"Reinhard expects NCHW images with C=3, got shape {tuple(images.shape)}")
 
+    def _workspace(self, n: int, h: int, w: int, ready: bool = False) -> torch.Tensor:
+        """The stream's workspace.  Its arrival counters lie where (n, h, w) puts them and are zero between calls OF THAT SHAPE: the
+        transform uses the entry point that relies on it (include/stainx_hip.h: sx_reinhard_transform_ready) and has the workspace
+        zero-filled first whenever the last call on it had another shape (or there was none)."""
+        ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+        shapes = self.__dict__.setdefault("_ws_shape", {})
+        key = (int(n), int(h), int(w))
+        if ready and shapes.get(ws.data_ptr()) != key:
+            _native.check(self._lib.sx_reinhard_workspace_init(ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device)), "sx_reinhard_workspace_init")
+        shapes[ws.data_ptr()] = key
+        self.last_workspace = ws
+        return ws
+
+    def workspace_status(self) -> int:
+        """Bit 0: a transform found the workspace not in its ready state (synchronises; for tests and diagnosis)."""
+        ws = getattr(self, "last_workspace", None)
+        off = int(self._lib.sx_reinhard_workspace_status_offset())
+        return 0 if ws is None else int(ws[off:off + 4].view(torch.int32).item())
+
     def compute_reference_mean_std(self, images: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         images = images.to(self.device)
         self._check(images)
@@ -371,7 +390,7 @@ class ReinhardHIP(TorchHIPBackendBase):
         mean = torch.empty(3, dtype=torch.float32, device=self.device)
         std = torch.empty(3, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+            ws = self._workspace(n, h, w)
             rc = self._lib.sx_reinhard_fit(images.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(), std.data_ptr(),
                                            ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_reinhard_fit")
@@ -391,10 +410,12 @@ class ReinhardHIP(TorchHIPBackendBase):
         if images.numel() == 0:
             return out
         with torch.cuda.device(self.device):
-            ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
-            rc = self._lib.sx_reinhard_transform(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(),
-                                                 std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
-        _native.check(rc, "sx_reinhard_transform")
+            ws = self._workspace(n, h, w, ready=True)
+            rc = self._lib.sx_reinhard_transform_ready(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(),
+                                                       std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        if rc != 0:
+            self.__dict__.get("_ws_shape", {}).pop(ws.data_ptr(), None)      # (a failed call may have left counters behind)
+        _native.check(rc, "sx_reinhard_transform_ready")
         return out
 
 
@@ -407,7 +428,7 @@ class ReinhardHIP(TorchHIPBackendBase):
         n, _, h, w = images.shape
         sums = torch.empty(6, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
-            ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+            ws = self._workspace(n, h, w)
             rc = self._lib.sx_reinhard_sums(images.data_ptr(), _dtype_code(images), n, h, w, sums.data_ptr(), ws.data_ptr(), ws.numel(),
                                             _native.stream_ptr(self.device))
         _native.check(rc, "sx_reinhard_sums")
@@ -422,7 +443,7 @@ class ReinhardHIP(TorchHIPBackendBase):
         n, _, h, w = images.shape
         out = torch.empty_like(images)
         with torch.cuda.device(self.device):
-            ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+            ws = self._workspace(n, h, w)
             rc = self._lib.sx_reinhard_apply(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, sums.data_ptr(), float(n_total_pixels),
                                              mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_reinhard_apply")

@@ -215,3 +215,49 @@ def test_histogram_matching_ready_workspace_calls(dev):
         assert torch.equal(be.transform(src, list(ref)), want)
     assert be.workspace_status() == 0
     assert int(be.tables()["counts"].sum()) == src.numel()
+
+
+def test_reinhard_ready_workspace_calls(dev):
+    """include/stainx_hip.h, sx_reinhard_transform_ready: the transform without the launch that clears the arrival counters.  Same bits
+    as the plain call; a workspace that was not ready is noticed; the backend re-initialises its workspace when the shape changes (the
+    counters lie where the shape puts them)."""
+    from stainx_amd import _native
+    from stainx_amd.backends.torch_hip_backend import ReinhardHIP
+
+    lib = _native.require()
+    be = ReinhardHIP(dev)
+    src = synth.as_dtype(synth.noise_u8((5, 3, 200, 328), 7), torch.float32).to(dev)
+    mean = torch.tensor([150.0, 130.0, 120.0], device=dev)
+    std = torch.tensor([40.0, 9.0, 12.0], device=dev)
+    n, _, h, w = src.shape
+    f32 = _native.DTYPE_CODES[torch.float32]
+    stream = _native.stream_ptr(dev)
+    ws = torch.full((int(lib.sx_reinhard_workspace_bytes(n, h, w)),), 0xA5, dtype=torch.uint8, device=dev)
+    off = int(lib.sx_reinhard_workspace_status_offset())
+
+    def status():
+        return int(ws[off:off + 4].view(torch.int32).item())
+
+    def run(fn):
+        out = torch.empty_like(src)
+        assert fn(src.data_ptr(), out.data_ptr(), f32, n, h, w, mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel(), stream) == 0
+        return out
+
+    want = run(lib.sx_reinhard_transform)                    # garbage in: the plain call clears what it needs
+    oracle = so.reinhard_transform(src.cpu().numpy(), mean.cpu().numpy(), std.cpu().numpy())
+    assert np.abs(want.cpu().numpy() - oracle).max() <= 1e-4
+    for _ in range(3):
+        assert torch.equal(run(lib.sx_reinhard_transform_ready), want) and status() == 0
+    ws.fill_(0x01)                                            # somebody else wrote here
+    run(lib.sx_reinhard_transform_ready)
+    assert status() & 1
+    assert lib.sx_reinhard_workspace_init(ws.data_ptr(), ws.numel(), stream) == 0
+    assert torch.equal(run(lib.sx_reinhard_transform_ready), want) and status() == 0
+    # the backend: shapes alternate on one workspace, a fit in between
+    small = src[:2, :, :64, :96].contiguous()
+    want_small = be.transform(small, mean, std)
+    for _ in range(2):
+        assert torch.equal(be.transform(src, mean, std), want) and be.workspace_status() == 0
+        be.compute_reference_mean_std(small)
+        assert torch.equal(be.transform(small, mean, std), want_small) and be.workspace_status() == 0
+        assert torch.equal(be.transform(src, mean, std), want)
