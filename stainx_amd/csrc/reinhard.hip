@@ -56,16 +56,62 @@ struct LinearTable {
     }
 };
 
-// f(X/Xn), f(Y), f(Z) of a linear-light pixel: everything of RGB -> LAB except the last affine step
-__device__ __forceinline__ void linear_to_f(const float lin[3], float f[3]) {
-    // torch_backend.py:32-38
-    const float x = (0.412453f * lin[0] + 0.357580f * lin[1] + 0.180423f * lin[2]) * (1.0f / 0.95047f);
-    const float y = (0.212671f * lin[0] + 0.715160f * lin[1] + 0.072169f * lin[2]);
-    const float z = (0.019334f * lin[0] + 0.119193f * lin[1] + 0.950227f * lin[2]) * (1.0f / 1.08883f);
-    const float xyz[3] = {x, y, z};
+// The two 3 x 3 colour matrices on the matrix core: a matrix-vector product per pixel is nine multiply-adds on the vector ALU, or three
+// v_mfma_f32_4x4x1 on a pipe that is otherwise idle (apply pass 448 -> 366 vector instructions per four pixels, statistics 245 -> 203;
+// 1-4 us per call on the boxes measured, inside their spread -- SQ counters put the vector ALU at 71 % / 58 % busy in the two passes, so
+// the instruction count is not the whole story; section 5 of DESIGN.md).  The instruction multiplies, in each of 16 blocks of four lanes, a 4 x 1 column (one element per lane: lane l
+// holds row l % 4)
+// with a 1 x 4 row (lane l holds column l % 4) and adds the 4 x 4 product to four registers per lane (register r of lane l: row r,
+// column l % 4).  With the matrix's column k spread over the four lanes of every block and the lane's OWN pixel component k as the
+// row element, three of them leave (M x)_r of the lane's pixel in register r.  fp32 throughout; the white point is folded into the
+// matrix (rows of the forward one, columns of the inverse), a difference of an ulp from the reference's separate division.
+typedef float float4v __attribute__((ext_vector_type(4)));
+struct MatrixLane {
+    float col[3];      // M[lane % 4][k] for k = 0..2 (row 3 of the 4 x 4 block: zeros)
+};
+__device__ __forceinline__ MatrixLane matrix_lane(const float (&m)[3][3]) {
+    const int r = (int)(lane_id() & 3u);
+    MatrixLane out;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)   // torch_backend.py:41-42
-        f[c] = xyz[c] > 0.008856f ? fast_pow(xyz[c], 1.0f / 3.0f) : 7.787f * xyz[c] + 16.0f / 116.0f;
+    for (int k = 0; k < 3; ++k) out.col[k] = r == 0 ? m[0][k] : r == 1 ? m[1][k] : r == 2 ? m[2][k] : 0.0f;
+    return out;
+}
+// (M x) for the V pixels of a pack, column by column: the V accumulator chains are independent, so no instruction waits for the one
+// before it (one pixel's three on their own are a dependent chain: the compiler pads it with s_nop)
+template <int V>
+__device__ __forceinline__ void matrix_times_pack(const MatrixLane& m, const float (&x)[V][3], float (&y)[V][3]) {
+    float4v d[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[i] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) d[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(m.col[k], x[i][k], d[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        y[i][0] = d[i][0];
+        y[i][1] = d[i][1];
+        y[i][2] = d[i][2];
+    }
+}
+// linear RGB -> XYZ / white point (torch_backend.py:32-38) and XYZ -> linear RGB with the white point folded in (:89-91)
+__device__ __forceinline__ MatrixLane forward_matrix() {
+    const float m[3][3] = {{0.412453f / 0.95047f, 0.357580f / 0.95047f, 0.180423f / 0.95047f},
+                           {0.212671f, 0.715160f, 0.072169f},
+                           {0.019334f / 1.08883f, 0.119193f / 1.08883f, 0.950227f / 1.08883f}};
+    return matrix_lane(m);
+}
+__device__ __forceinline__ MatrixLane inverse_matrix() {
+    const float m[3][3] = {{3.2404542f * 0.95047f, -1.5371385f, -0.4985314f * 1.08883f},
+                           {-0.9692660f * 0.95047f, 1.8760108f, 0.0415560f * 1.08883f},
+                           {0.0556434f * 0.95047f, -0.2040259f, 1.0572252f * 1.08883f}};
+    return matrix_lane(m);
+}
+
+// f(t) of torch_backend.py:41-42 for the three components of X/Xn, Y, Z/Zn: everything of RGB -> LAB except the last affine step
+__device__ __forceinline__ void xyz_to_f(const float xyz[3], float f[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[c] = xyz[c] > 0.008856f ? fast_pow(xyz[c], 1.0f / 3.0f) : 7.787f * xyz[c] + 16.0f / 116.0f;
 }
 
 // LAB (scaled to 0..255 as the reference does, torch_backend.py:51-53) is AFFINE in e = (f_y, f_x - f_y, f_y - f_z):
@@ -82,25 +128,24 @@ __device__ __forceinline__ void f_to_e(const float f[3], float e[3]) {
     e[2] = f[1] - f[2];
 }
 
-__device__ __forceinline__ void rgb_to_f(const float rgb[3], float f[3]) {
-    float lin[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) lin[c] = srgb_to_linear(rgb[c]);
-    linear_to_f(lin, f);
-}
-
-// e (see above) of pixel i of the loaded packs: through the table for uint8 (u holds grey levels), through the formula otherwise (unit values)
+// e (see above) of the V pixels of the loaded packs: the linear-light values through the table for uint8 (u holds grey levels), through
+// the formula otherwise (unit values); then the matrix for the whole pack, then f and e
 template <typename T, int V>
-__device__ __forceinline__ void pixel_to_e(const float (&u)[3][V], int i, const LinearTable* table, float e[3]) {
-    float f[3];
-    if constexpr (sizeof(T) == 1) {
-        const float lin[3] = {table->lin[(int)u[0][i]], table->lin[(int)u[1][i]], table->lin[(int)u[2][i]]};
-        linear_to_f(lin, f);
-    } else {
-        const float rgb[3] = {u[0][i], u[1][i], u[2][i]};
-        rgb_to_f(rgb, f);
+__device__ __forceinline__ void pack_to_e(const float (&u)[3][V], const LinearTable* table, const MatrixLane& fwd, float (&e)[V][3]) {
+    float lin[V][3], xyz[V][3];
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (sizeof(T) == 1) lin[i][c] = table->lin[(int)u[c][i]]; else lin[i][c] = srgb_to_linear(u[c][i]);
+        }
+    matrix_times_pack<V>(fwd, lin, xyz);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        float f[3];
+        xyz_to_f(xyz[i], f);
+        f_to_e(f, e[i]);
     }
-    f_to_e(f, e);
 }
 // (uint8: the packs are loaded as grey levels, not unit values)
 template <typename T, int V>
@@ -123,13 +168,10 @@ __device__ __forceinline__ void load_for_lab_last(const T* __restrict__ p, float
 
 __device__ __forceinline__ float f_inv(float t) { return t > 0.2068966f ? t * t * t : (t - 16.0f / 116.0f) * (1.0f / 7.787f); }   // :78-80
 
-// (fy = (L / 2.55 + 16) / 116, fx = (a - 128) / 500 + fy, fz = fy - (b - 128) / 200, :70-72, are the caller's: folded into its constants)
-__device__ __forceinline__ void f_to_rgb(float fx, float fy, float fz, float rgb[3]) {
-    const float x = f_inv(fx) * 0.95047f, y = f_inv(fy), z = f_inv(fz) * 1.08883f;
-    const float lin[3] = {3.2404542f * x - 1.5371385f * y - 0.4985314f * z, -0.9692660f * x + 1.8760108f * y + 0.0415560f * z,
-                          0.0556434f * x - 0.2040259f * y + 1.0572252f * z};   // :89-91
+// linear RGB -> sRGB, clamped (:93-96)
+__device__ __forceinline__ void linear_to_rgb(const float lin[3], float rgb[3]) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {   // :93-96
+    for (int c = 0; c < 3; ++c) {
         const float v = lin[c] > 0.0031308f ? 1.055f * fast_pow(lin[c], 1.0f / 2.4f) - 0.055f : 12.92f * lin[c];
         rgb[c] = fminf(fmaxf(v, 0.0f), 1.0f);
     }
@@ -150,22 +192,24 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
     const T* img = images + tile * 3 * g.pixels;
     __shared__ LinearTable table;
     if constexpr (sizeof(T) == 1) table.fill();
+    const MatrixLane fwd = forward_matrix();
     double acc[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+    // (requesting the next trip's packs before working on this trip's changes nothing: 55.1 against 55.5 us)
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
         float u[3][V];
 #pragma unroll
         for (int c = 0; c < 3; ++c) load_for_lab<T, V>(img + c * g.pixels + p, u[c]);
         float s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+        float e[V][3];
+        pack_to_e<T, V>(u, &table, fwd, e);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            float e[3];
-            pixel_to_e<T, V>(u, i, &table, e);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                s[c] += e[c];
-                q[c] = fmaf(e[c], e[c], q[c]);
+                s[c] += e[i][c];
+                q[c] = fmaf(e[i][c], e[i][c], q[c]);
             }
         }
 #pragma unroll
@@ -271,18 +315,28 @@ __global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restri
     }
     __shared__ LinearTable table;
     if constexpr (sizeof(T) == 1) table.fill();
+    const MatrixLane fwd = forward_matrix(), inv = inverse_matrix();
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
         float u[3][V];
 #pragma unroll
         for (int c = 0; c < 3; ++c) load_for_lab_last<T, V>(img + c * g.pixels + p, u[c]);
         T res[3][V];
+        float e[V][3], xyz[V][3], lin[V][3];
+        pack_to_e<T, V>(u, &table, fwd, e);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            float e[3], back[3];
-            pixel_to_e<T, V>(u, i, &table, e);
-            const float fy = fmaf(k[0], e[0], cst[0]);
-            const float fx = fmaf(k[1], e[1], fy + cst[1]), fz = fy - fmaf(k[2], e[2], cst[2]);
-            f_to_rgb(fx, fy, fz, back);
+            // (fy = (L / 2.55 + 16) / 116, fx = (a - 128) / 500 + fy, fz = fy - (b - 128) / 200, :70-72: folded into k and cst)
+            const float fy = fmaf(k[0], e[i][0], cst[0]);
+            const float fx = fmaf(k[1], e[i][1], fy + cst[1]), fz = fy - fmaf(k[2], e[i][2], cst[2]);
+            xyz[i][0] = f_inv(fx);
+            xyz[i][1] = f_inv(fy);
+            xyz[i][2] = f_inv(fz);
+        }
+        matrix_times_pack<V>(inv, xyz, lin);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float back[3];
+            linear_to_rgb(lin[i], back);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 if constexpr (sizeof(T) == 1)
