@@ -166,6 +166,35 @@ int sx_macenko_pfit_finish(const unsigned* gathered_compact_dev, const int* gath
                            float* he_out_dev, float* max_c_out_dev, int* status_out_dev, void* workspace_dev,
                            size_t workspace_bytes, void* stream);
 
+/* The same steps with what travels through a collective PACKED AND UNPACKED BY THE LIBRARY: one contiguous record per rank and
+ * exchange, so the host side is an all-gather / all-reduce of a buffer it never looks into (the unpacked steps above cost the
+ * host a dozen small tensor operations per exchange: a third of a pooled fit_transform step).
+ *   stats record  [int64 tiles | 10 fp64 moments | 3 x 4096 fp32 sample]                  SX_PFIT_STATS_RECORD_BYTES, 8-byte aligned
+ *   stage record  [int32 count, count, stale flag | 2 x share uint32 candidate keys]      (3 + 2 share) x 4 bytes
+ *   sx_macenko_pfit_stats_packed   the rank's stats record -> all-gather
+ *   sx_macenko_pfit_plane_packed   every rank's record [world][record]: moments added up in rank order, the union sample (every
+ *                                  world-th column of every rank, ranks one after the other, cut at 4096; sample_counts_host[r] =
+ *                                  sx_macenko_pfit_sample_count of rank r's tiles, a HOST array), and -- if expected_tiles_dev
+ *                                  is given -- *stale_out_dev = 1 when some rank's tile count differs from it (the host may take
+ *                                  the counts of the last call on trust and have them checked here), else 0
+ *   sx_macenko_pfit_gather_packed  as sx_macenko_pfit_gather; writes the rank's stage record, stale_flag_dev (may be null) into it
+ *   sx_macenko_pfit_finish_packed  as sx_macenko_pfit_finish on the gathered stage records [world][3 + 2 share]; any rank's stale
+ *                                  flag sets bit 4 (16) of *status_out (bits 0-3: brackets that did not hold) */
+#define SX_PFIT_STATS_RECORD_BYTES 49240
+int sx_macenko_pfit_stats_packed(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
+                                 void* record_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int sx_macenko_pfit_plane_packed(const void* gathered_records_dev, int world, const int* sample_counts_host,
+                                 const long long* expected_tiles_dev, int* stale_out_dev, long long n_all, int sample_count,
+                                 int64_t n_tiles, int64_t height, int64_t width, void* workspace_dev, size_t workspace_bytes,
+                                 void* stream);
+int sx_macenko_pfit_gather_packed(const long long* sums_global_dev, int stage, long long n_all, int sample_count,
+                                  int64_t n_tiles, int64_t height, int64_t width, int share, const int* stale_flag_dev,
+                                  unsigned* record_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int sx_macenko_pfit_finish_packed(const unsigned* gathered_records_dev, int world, int share, int stage, long long n_all,
+                                  int sample_count, int64_t n_tiles, int64_t height, int64_t width, float* he_out_dev,
+                                  float* max_c_out_dev, int* status_out_dev, void* workspace_dev, size_t workspace_bytes,
+                                  void* stream);
+
 /* ---------------------------------------------------------------- Reinhard -----------------------
  * Replaces stainx_cuda_torch.reinhard (bindings.cpp:32) with the numerics of ReinhardTorch
  * (torch_backend.py:304-355): LAB statistics pooled over the whole batch, unbiased std. */

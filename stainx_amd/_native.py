@@ -28,6 +28,7 @@ MACENKO_SPEC_FAIL = 128
 MACENKO_TWO_PASS = 256
 MACENKO_FUSE = 512
 MACENKO_PARAM_FLOATS = 48
+PFIT_STATS_RECORD_BYTES = 49240
 PFIT_SUMS = 1033
 PFIT_COMPACT = 32768
 
@@ -60,6 +61,10 @@ SIGNATURES = {
     "sx_macenko_pfit_pass": (_int, [_vp, _int, _i64, _i64, _i64, _int, _c.c_longlong, _int, _vp, _vp, _sz, _vp]),
     "sx_macenko_pfit_gather": (_int, [_vp, _int, _c.c_longlong, _int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "sx_macenko_pfit_finish": (_int, [_vp, _vp, _int, _int, _int, _c.c_longlong, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sx_macenko_pfit_stats_packed": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "sx_macenko_pfit_plane_packed": (_int, [_vp, _int, _vp, _vp, _vp, _c.c_longlong, _int, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "sx_macenko_pfit_gather_packed": (_int, [_vp, _int, _c.c_longlong, _int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sx_macenko_pfit_finish_packed": (_int, [_vp, _int, _int, _int, _c.c_longlong, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sx_reinhard_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "sx_reinhard_sums": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sx_reinhard_apply": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _c.c_double, _vp, _vp, _vp, _sz, _vp]),

@@ -9,6 +9,7 @@ torch_backend.py:463-466) -- there is no torch-op or CPU path in this package.
 """
 from __future__ import annotations
 
+import ctypes as _c
 import os
 import threading
 
@@ -315,7 +316,7 @@ class MacenkoHIP(TorchHIPBackendBase):
     def pfit_gather(self, sums_global: torch.Tensor, stage: int, n_all: int, sample_count: int, shape: tuple[int, int, int], share: int) -> tuple[torch.Tensor, torch.Tensor]:
         n, h, w = shape
         sums_global = sums_global.to(self.device, torch.int64).contiguous()
-        compact = torch.zeros((2, int(share)), dtype=torch.int32, device=self.device)
+        compact = torch.empty((2, int(share)), dtype=torch.int32, device=self.device)      # (only the first `counts` entries of a row are written and read: no fill)
         counts = torch.empty(2, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             ws = self._pfit_ws(n, h, w)
@@ -338,6 +339,69 @@ class MacenkoHIP(TorchHIPBackendBase):
             rc = self._lib.sx_macenko_pfit_finish(gathered_compact.data_ptr(), gathered_counts.data_ptr(), world, share, int(stage), int(n_all), int(sample_count), n, h, w,
                                                   he.data_ptr(), max_c.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_pfit_finish")
+        self.last_workspace = ws
+        return (he, max_c, status) if stage == 1 else None
+
+    # ---- the same steps with the records of the exchanges packed and unpacked by the library (include/stainx_hip.h) ----
+    def pfit_stats_packed(self, images: torch.Tensor) -> torch.Tensor:
+        """This rank's stats record [int64 tiles | 10 fp64 moments | 3 x 4096 fp32 sample] as bytes, ready for the all-gather."""
+        images = images.to(self.device)
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"Macenko fit expects NCHW with C=3, got shape {tuple(images.shape)}")
+        images = images.contiguous()
+        n, _, h, w = images.shape
+        record = torch.empty(_native.PFIT_STATS_RECORD_BYTES, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_stats_packed(images.data_ptr(), _dtype_code(images), n, h, w, record.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_stats_packed")
+        self.last_workspace = ws
+        return record
+
+    def pfit_empty_record(self) -> torch.Tensor:
+        """The record of a rank without tiles (it still takes part in the exchange that tells every rank so)."""
+        return torch.zeros(_native.PFIT_STATS_RECORD_BYTES, dtype=torch.uint8, device=self.device)
+
+    def pfit_plane_packed(self, gathered: torch.Tensor, sample_counts: list[int], expected_tiles: torch.Tensor | None, n_all: int, sample_count: int,
+                          shape: tuple[int, int, int]) -> torch.Tensor:
+        """Every rank's stats record (world, record bytes) -> plane and angle brackets; returns the one-element int32 "some rank's
+        tile count is not the expected one" flag (zero without `expected_tiles`)."""
+        n, h, w = shape
+        world = int(gathered.shape[0])
+        gathered = gathered.contiguous()
+        counts = (_c.c_int * world)(*[int(v) for v in sample_counts])
+        stale = torch.empty(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_plane_packed(gathered.data_ptr(), world, _c.cast(counts, _c.c_void_p), expected_tiles.data_ptr() if expected_tiles is not None else None,
+                                                        stale.data_ptr(), int(n_all), int(sample_count), n, h, w, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_plane_packed")
+        return stale
+
+    def pfit_gather_packed(self, sums_global: torch.Tensor, stage: int, n_all: int, sample_count: int, shape: tuple[int, int, int], share: int, stale: torch.Tensor | None) -> torch.Tensor:
+        n, h, w = shape
+        sums_global = sums_global.to(self.device, torch.int64).contiguous()
+        row = torch.empty(3 + 2 * int(share), dtype=torch.int32, device=self.device)      # (only the counted entries are written and read: no fill)
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_gather_packed(sums_global.data_ptr(), int(stage), int(n_all), int(sample_count), n, h, w, int(share),
+                                                         stale.data_ptr() if stale is not None else None, row.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_gather_packed")
+        return row
+
+    def pfit_finish_packed(self, gathered_rows: torch.Tensor, stage: int, n_all: int, sample_count: int, shape: tuple[int, int, int], share: int):
+        """Stage 0: nothing returned.  Stage 1: (HE, maxC, status) -- bits 0-3 of the device int32: a bracket missed; bit 4: a stale flag."""
+        n, h, w = shape
+        world = int(gathered_rows.shape[0])
+        gathered_rows = gathered_rows.contiguous()
+        he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
+        max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
+        status = torch.empty(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            ws = self._pfit_ws(n, h, w)
+            rc = self._lib.sx_macenko_pfit_finish_packed(gathered_rows.data_ptr(), world, int(share), int(stage), int(n_all), int(sample_count), n, h, w, he.data_ptr(), max_c.data_ptr(),
+                                                         status.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
+        _native.check(rc, "sx_macenko_pfit_finish_packed")
         self.last_workspace = ws
         return (he, max_c, status) if stage == 1 else None
 

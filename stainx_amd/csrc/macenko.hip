@@ -2859,10 +2859,11 @@ constexpr int kPoolSums = 1024 + 2 * kSlots + 1;      // hist[2][2][256], below[
 static_assert(kPoolSums == SX_PFIT_SUMS, "header constant");
 
 // local partial moments -> 10 doubles; the local sample (group 0) -> caller buffer
-__global__ __launch_bounds__(256) void pfit_export_stats_kernel(Workspace ws, int64_t nblk, double* __restrict__ moments_out, float* __restrict__ sample_out) {
+__global__ __launch_bounds__(256) void pfit_export_stats_kernel(Workspace ws, int64_t nblk, double* __restrict__ moments_out, float* __restrict__ sample_out, long long* __restrict__ tiles_out = nullptr, long long tiles = 0) {
     if (blockIdx.x == 0) {
         const double s = reduce_partials(ws.partial, nblk);
         if (threadIdx.x < kPartial) moments_out[threadIdx.x] = s;
+        if (tiles_out && threadIdx.x == 0) tiles_out[0] = tiles;      // (the packed record: the tile count leads it)
     } else {
         for (int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x; i < 3 * kSample; i += (gridDim.x - 1) * blockDim.x) sample_out[i] = ws.sample_od[i];
     }
@@ -2937,6 +2938,94 @@ __global__ void pfit_merge_kernel(Workspace ws, int stage, int world, int share,
 
 __global__ void pfit_status_kernel(Workspace ws, int* __restrict__ status_out) {
     if (threadIdx.x == 0) status_out[0] = (int)(ws.pool->status | (ws.state[0].fell_back & 0xFu));
+}
+
+// ---- the same exchanges with the records packed and unpacked HERE (sx_macenko_pfit_*_packed) ----------------------------------
+// What travels through a collective is one contiguous record per rank, written and read by these kernels: the host side of the
+// unpacked steps did that with a dozen small tensor operations per exchange (cat, slices made contiguous, zero fills, comparisons,
+// reductions), ~5 us of launch and gap each -- a third of a pooled fit_transform step.
+//   stats record   [int64 tiles | 10 fp64 moments | 3 x 4096 fp32 sample]                      (kPfitStatsRecord bytes)
+//   stage record   [int32 count_lo, count_hi, stale flag | 2 x share uint32 candidate keys]    (12 + 8 share bytes)
+constexpr size_t kPfitStatsRecord = 8 + 8 * kPartial + 4 * 3 * (size_t)kSample;
+static_assert(kPartial == 10 && kPfitStatsRecord == SX_PFIT_STATS_RECORD_BYTES, "header constant");
+struct PfitRanks {
+    int world;
+    int sample_counts[64];      // valid columns of every rank's sample
+};
+
+// every rank's stats record -> the moments added up in rank order, the union sample (every world-th column of every rank's sample,
+// ranks one after the other, cut at 4096; what stainx_amd/distributed.py assembled with slices), and "some rank's tile count is not
+// the one the host took on trust"
+__global__ __launch_bounds__(256) void pfit_unpack_stats_kernel(Workspace ws, const unsigned char* __restrict__ gathered, PfitRanks ranks, const long long* __restrict__ expected_tiles, int* __restrict__ stale_out,
+                                                                double* __restrict__ moments_out) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < kPartial) {
+            double s = 0.0;
+            for (int r = 0; r < ranks.world; ++r) s += reinterpret_cast<const double*>(gathered + (size_t)r * kPfitStatsRecord + 8)[threadIdx.x];
+            moments_out[threadIdx.x] = s;
+        }
+        if (threadIdx.x == 64 && stale_out) {
+            int stale = 0;
+            if (expected_tiles)
+                for (int r = 0; r < ranks.world; ++r) stale |= reinterpret_cast<const long long*>(gathered + (size_t)r * kPfitStatsRecord)[0] != expected_tiles[r];
+            stale_out[0] = stale;
+        }
+        return;
+    }
+    for (int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x; i < 3 * kSample; i += (gridDim.x - 1) * blockDim.x) {
+        const int ch = i / kSample, pos = i % kSample;
+        float v = 0.0f;
+        int base = 0;
+        for (int r = 0; r < ranks.world; ++r) {
+            const int len = (ranks.sample_counts[r] + ranks.world - 1) / ranks.world;      // columns 0, world, 2 world, ... below the rank's count
+            if (pos < base + len) {
+                v = reinterpret_cast<const float*>(gathered + (size_t)r * kPfitStatsRecord + 8 + 8 * kPartial)[(size_t)ch * kSample + (size_t)(pos - base) * ranks.world];
+                break;
+            }
+            base += len;
+        }
+        ws.sample_od[i] = v;
+    }
+}
+
+// the rank's stage record: counts, the stale flag, its candidates of the picked bin
+__global__ void pfit_export_row_kernel(Workspace ws, int stage, int share, const int* __restrict__ stale_flag, unsigned* __restrict__ row_out) {
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t n = ws.pool->compact_n[2 * stage + j];
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < min(n, (uint32_t)share); i += gridDim.x * blockDim.x) row_out[3 + (size_t)j * share + i] = ws.pool->compact[2 * stage + j][i];
+        if (blockIdx.x == 0 && threadIdx.x == 0) row_out[j] = n;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) row_out[2] = stale_flag ? (unsigned)stale_flag[0] : 0u;
+}
+
+// the ranks' stage records, gathered -> the union of the candidates in the pool; any rank's stale flag -> bit 4 of the pool's status
+__global__ void pfit_merge_rows_kernel(Workspace ws, int stage, int world, int share, const unsigned* __restrict__ rows) {
+    __shared__ uint32_t base[64][2];
+    const size_t stride = 3 + 2 * (size_t)share;
+    if (threadIdx.x < 2) {
+        uint32_t run = 0;
+        bool bad = false;
+        for (int r = 0; r < world; ++r) {
+            base[r][threadIdx.x] = run;
+            const int n = (int)rows[r * stride + threadIdx.x];
+            if (n > share) bad = true;
+            run += (uint32_t)min(n, share);
+        }
+        ws.pool->compact_n[2 * stage + threadIdx.x] = run;
+        if (bad || run > (uint32_t)kCompact) ws.pool->status = 1u;
+    }
+    if (threadIdx.x == 64) {
+        unsigned stale = 0;
+        for (int r = 0; r < world; ++r) stale |= rows[r * stride + 2];
+        if (stale) atomicOr(&ws.pool->status, 16u);      // (bits 0-3: a bracket that did not hold / the slots that fell back)
+    }
+    __syncthreads();
+    for (int r = 0; r < world; ++r)
+        for (int j = 0; j < 2; ++j) {
+            const int n = min((int)rows[r * stride + j], share);
+            for (int i = threadIdx.x; i < n; i += blockDim.x)
+                if (base[r][j] + i < (uint32_t)kCompact) ws.pool->compact[2 * stage + j][base[r][j] + i] = rows[r * stride + 3 + (size_t)j * share + i];
+        }
 }
 
 // ---- distributed pooled fit: staged entry points (host does the all-reduces in between) -----------
@@ -3223,6 +3312,81 @@ extern "C" int sx_macenko_pfit_plane(const double* moments, long long n_all, con
     hipLaunchKernelGGL(pfit_import_sample_kernel, dim3(12), dim3(256), 0, stream, ws, sample_union);
     hipLaunchKernelGGL(pfit_plane_kernel, dim3(1), dim3(kGroupThreads), 0, stream, g, ws, moments);
     return check_launch("macenko pfit plane");
+}
+
+extern "C" int sx_macenko_pfit_stats_packed(const void* images, int dtype, int64_t n, int64_t h, int64_t w, void* record_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    if (!record_out || reinterpret_cast<uintptr_t>(record_out) % 8 != 0) return fail(SX_ERR_BAD_ARG, "record_out is null or not 8-byte aligned");
+    unsigned char* rec = static_cast<unsigned char*>(record_out);
+    int rc = validate_images(images, n, h, w, ws_ptr, ws_bytes, macenko::workspace_bytes(n, h * w, kWsBase));
+    if (rc != SX_OK) return rc;
+    const Geometry g = pfit_geometry(n, h, w, 0, -1);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    switch (dtype) {
+        case SX_U8: rc = pfit_pass_typed<uint8_t>(images, g, ws, -1, nullptr, stream); break;
+        case SX_F16: rc = pfit_pass_typed<__half>(images, g, ws, -1, nullptr, stream); break;
+        case SX_BF16: rc = pfit_pass_typed<__hip_bfloat16>(images, g, ws, -1, nullptr, stream); break;
+        case SX_F32: rc = pfit_pass_typed<float>(images, g, ws, -1, nullptr, stream); break;
+        case SX_F64: rc = pfit_pass_typed<double>(images, g, ws, -1, nullptr, stream); break;
+        default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
+    }
+    if (rc != SX_OK) return rc;
+    hipLaunchKernelGGL(pfit_export_stats_kernel, dim3(13), dim3(256), 0, stream, ws, (int64_t)(g.n_tiles * g.blocks_per_tile), reinterpret_cast<double*>(rec + 8),
+                       reinterpret_cast<float*>(rec + 8 + 8 * kPartial), reinterpret_cast<long long*>(rec), (long long)n);
+    return check_launch("macenko pfit stats export (packed)");
+}
+
+extern "C" int sx_macenko_pfit_plane_packed(const void* gathered, int world, const int* sample_counts_host, const long long* expected_tiles, int* stale_out, long long n_all, int sample_count, int64_t n, int64_t h,
+                                            int64_t w, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    if (!gathered || !sample_counts_host || !ws_ptr || world < 1 || world > 64) return fail(SX_ERR_BAD_ARG, "null pointer or world size outside 1..64");
+    if (n <= 0 || h <= 0 || w <= 0 || n_all <= 0 || sample_count < 0 || sample_count > kSample) return fail(SX_ERR_BAD_ARG, "bad sizes");
+    if (ws_bytes < macenko::workspace_bytes(n, h * w, kWsBase)) return fail(SX_ERR_WORKSPACE, "workspace too small");
+    PfitRanks ranks{};
+    ranks.world = world;
+    for (int r = 0; r < world; ++r) {
+        if (sample_counts_host[r] < 0 || sample_counts_host[r] > kSample) return fail(SX_ERR_BAD_ARG, "sample count of rank %d outside 0..%d", r, kSample);
+        ranks.sample_counts[r] = sample_counts_host[r];
+    }
+    const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    double* moments = reinterpret_cast<double*>(ws.pool->compact[kSlots - 1] + kCompact - 32);      // (scratch: the tail of the last compact list, free until the second stage's merge)
+    hipLaunchKernelGGL(pfit_unpack_stats_kernel, dim3(13), dim3(256), 0, stream, ws, static_cast<const unsigned char*>(gathered), ranks, expected_tiles, stale_out, moments);
+    hipLaunchKernelGGL(pfit_plane_kernel, dim3(1), dim3(kGroupThreads), 0, stream, g, ws, moments);
+    return check_launch("macenko pfit plane (packed)");
+}
+
+extern "C" int sx_macenko_pfit_gather_packed(const long long* sums_global, int stage, long long n_all, int sample_count, int64_t n, int64_t h, int64_t w, int share, const int* stale_flag, unsigned* row_out,
+                                             void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    if (share < 1 || share > kCompact) return fail(SX_ERR_BAD_ARG, "share must be in [1, %d]", kCompact);
+    if (!sums_global || !row_out || !ws_ptr || (stage != 0 && stage != 1)) return fail(SX_ERR_BAD_ARG, "null pointer or bad stage");
+    if (n <= 0 || h <= 0 || w <= 0 || ws_bytes < macenko::workspace_bytes(n, h * w, kWsBase)) return fail(SX_ERR_WORKSPACE, "bad sizes or workspace too small");
+    const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    hipLaunchKernelGGL(pfit_import_sums_kernel, dim3(1), dim3(256), 0, stream, ws, sums_global, stage);
+    hipLaunchKernelGGL(pool_gather_kernel, dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, g, ws, stage);
+    hipLaunchKernelGGL(pfit_export_row_kernel, dim3(8), dim3(256), 0, stream, ws, stage, share, stale_flag, row_out);
+    return check_launch("macenko pfit gather (packed)");
+}
+
+extern "C" int sx_macenko_pfit_finish_packed(const unsigned* gathered_rows, int world, int share, int stage, long long n_all, int sample_count, int64_t n, int64_t h, int64_t w, float* he_out, float* max_c_out,
+                                             int* status_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
+    if (!gathered_rows || !ws_ptr || (stage != 0 && stage != 1) || world < 1 || world > 64) return fail(SX_ERR_BAD_ARG, "null pointer, bad stage or world size");
+    if (stage == 1 && (!he_out || !max_c_out || !status_out)) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out / status_out pointer is null");
+    if (n <= 0 || h <= 0 || w <= 0 || ws_bytes < macenko::workspace_bytes(n, h * w, kWsBase)) return fail(SX_ERR_WORKSPACE, "bad sizes or workspace too small");
+    if (share < 1 || (long long)world * share > kCompact) return fail(SX_ERR_BAD_ARG, "world x share = %d x %d exceeds the compact list (%d)", world, share, kCompact);
+    const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
+    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    hipLaunchKernelGGL(pfit_merge_rows_kernel, dim3(1), dim3(1024), 0, stream, ws, stage, world, share, gathered_rows);
+    if (stage == 0) {
+        hipLaunchKernelGGL((stain_kernel<float, true>), dim3(1), dim3(kGroupThreads), 0, stream, (const float*)nullptr, g, ws);
+    } else {
+        hipLaunchKernelGGL((scale_kernel<float, true>), dim3(1), dim3(kGroupThreads), 0, stream, (const float*)nullptr, g, ws, (const float*)nullptr, he_out, max_c_out);
+        hipLaunchKernelGGL(pfit_status_kernel, dim3(1), dim3(64), 0, stream, ws, status_out);
+    }
+    return check_launch("macenko pfit finish (packed)");
 }
 
 extern "C" int sx_macenko_pfit_pass(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int stage, long long n_all, int sample_count, long long* sums_out, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {

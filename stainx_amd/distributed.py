@@ -123,7 +123,11 @@ def all_gather_stack(t: torch.Tensor, group=None, force: bool | None = None) -> 
         parts = [torch.empty_like(host) for _ in range(size)]
         dist.all_gather(parts, host, group=group)
         return torch.stack(parts).to(t.device)
-    parts = [torch.empty_like(t) for _ in range(size)]
+    if t.is_cuda:      # RCCL: straight into the stacked result (a list of parts and torch.stack was one more copy kernel per exchange)
+        out = torch.empty((size, *t.shape), dtype=t.dtype, device=t.device)
+        _timed(dist.all_gather_into_tensor, out, t.contiguous(), group=group)
+        return out
+    parts = [torch.empty_like(t) for _ in range(size)]      # (gloo has no all_gather_into_tensor)
     _timed(dist.all_gather, parts, t.contiguous(), group=group)
     return torch.stack(parts)
 
@@ -200,7 +204,7 @@ def _macenko_fit_pooled(local_images, group, steps, method: str, defer_status: b
         code = int(status.item())
         if code == 0:
             return he, max_c, None
-        if code & 2 and not _retried:      # the cached tile counts were stale: once more with fresh ones (still the bracket form)
+        if code & 16 and not _retried:      # the cached tile counts were stale: once more with fresh ones (still the bracket form)
             _TILE_COUNTS.clear()
             return _macenko_fit_pooled(local_images, group, steps, method, defer_status, _retried=True)
         # (anything else -- a bracket that missed, or a stale flag that survives fresh counts -- goes on to the radix rounds below)
@@ -223,6 +227,21 @@ def _exchange_device(steps, local_images: torch.Tensor):
     return steps.device if hasattr(steps, "device") else local_images.device
 
 
+_COUNT_BYTES: dict = {}
+
+
+def _count_bytes(n: int, device) -> torch.Tensor:
+    """The tile count as the eight bytes that lead a rank's record in the packed all-gather; kept per (count, device) -- a loop calls
+    with the same count step after step, and a fresh torch.full is a fill kernel each time."""
+    key = (int(n), str(device))
+    t = _COUNT_BYTES.get(key)
+    if t is None:
+        if len(_COUNT_BYTES) > 64:
+            _COUNT_BYTES.clear()
+        t = _COUNT_BYTES[key] = torch.full((1,), int(n), dtype=torch.int64, device=device).view(torch.uint8)
+    return t
+
+
 def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _share: int | None = None):
     """-> (HE, maxC, status): status is a one-element int32 tensor, non-zero if a bracket missed (the caller then repeats the fit
     with the radix rounds)."""
@@ -232,6 +251,8 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _shar
     skip = _skip_collective(world(group)[1], None)
     if int(n) <= 0 and skip:
         raise ValueError(f"every rank needs at least one tile for a pooled statistic, got tiles per rank {[int(n)]}")
+    if not skip and hasattr(steps, "pfit_stats_packed"):
+        return _macenko_fit_pooled_brackets_packed(local_images, group, steps, shape, _share)
     if int(n) > 0:
         moments, sample = steps.pfit_stats(local_images)
     else:      # a rank without tiles still has to take part in the exchange that tells every rank so
@@ -240,8 +261,7 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _shar
         tiles, union, sample_count = [int(n)], sample, steps.pfit_sample_count(int(n), int(h), int(w))
     else:
         # ONE all-gather carries what used to be three exchanges: tile count, moments, pixel sample -- as bytes
-        mine = torch.cat([torch.full((1,), int(n), dtype=torch.int64, device=moments.device).view(torch.uint8), moments.contiguous().view(torch.uint8),
-                          sample.contiguous().view(torch.uint8).flatten()])
+        mine = torch.cat([_count_bytes(int(n), moments.device), moments.contiguous().view(torch.uint8), sample.contiguous().view(torch.uint8).flatten()])
         got = all_gather_stack(mine, group)                                                   # (world, 8 + 80 + 49152)
         counts_dev = got[:, :8].contiguous().view(torch.int64).flatten()
         # The ranks' tile counts are needed on the HOST (pixel total, sample layout, the compact list's split), and reading them
@@ -268,8 +288,11 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _shar
         else:
             cat = torch.cat([samples[r][:, : counts[r] : size] for r in range(size)], dim=1)[:, :4096]
         sample_count = int(cat.shape[1])
-        union = torch.zeros((3, 4096), dtype=torch.float32, device=cat.device)
-        union[:, :sample_count] = cat
+        if sample_count == 4096:
+            union = cat.contiguous()      # (the usual case: nothing to pad)
+        else:
+            union = torch.zeros((3, 4096), dtype=torch.float32, device=cat.device)
+            union[:, :sample_count] = cat
     n_all = int(sum(tiles)) * int(h) * int(w)
     if n_all >= 1 << 32:
         raise ValueError(f"a pooled fit over {n_all} pixels exceeds the 2^32 the native counters hold; fit on a subset of the tiles")
@@ -290,11 +313,48 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _shar
             flag = stale.to(counts.device) if stale is not None else torch.zeros(1, dtype=torch.int32, device=counts.device)
             got = all_gather_stack(torch.cat([counts.to(torch.int32).flatten(), flag.to(torch.int32), compact.to(torch.int32).flatten()]), group)
             g_counts, g_compact = got[:, :2], got[:, 3:].reshape(size, 2, share)
-            any_stale = got[:, 2].max().reshape(1)
+            if stage == 1:
+                any_stale = got[:, 2].max().reshape(1)      # (the flag is the same in both stages' exchanges)
         out = steps.pfit_finish(g_compact, g_counts, stage, n_all, sample_count, shape)
     if any_stale is not None:
         he, max_c, status = out
-        out = (he, max_c, status + 2 * any_stale.to(device=status.device, dtype=status.dtype))      # (bit 1: some rank's cached tile counts were not this call's)
+        out = (he, max_c, torch.add(status, any_stale.to(device=status.device, dtype=status.dtype), alpha=16))      # (bit 4: some rank's cached tile counts were not this call's)
+    return out
+
+
+def _macenko_fit_pooled_brackets_packed(local_images: torch.Tensor, group, steps, shape: tuple[int, int, int], _share: int | None):
+    """The five exchanges with the records packed and unpacked by the steps provider (include/stainx_hip.h, sx_macenko_pfit_*_packed):
+    the host moves buffers it never looks into -- except the ranks' tile counts, once per (group, local shape)."""
+    n, h, w = shape
+    record = steps.pfit_stats_packed(local_images) if n > 0 else steps.pfit_empty_record()
+    got = all_gather_stack(record, group)                                                     # (world, record bytes)
+    size = int(got.shape[0])
+    # the ranks' tile counts are needed on the HOST (pixel total, sample layout, the compact list's split); a loop calls with the same
+    # sharding step after step: the counts of the last call with this key are taken on trust and checked on the device against what
+    # the all-gather brought -- the flag travels with the stage records and ends in the status word (bit 4)
+    key = ("packed", id(group) if group is not None else 0, n, h, w, size, str(got.device))
+    cached = _TILE_COUNTS.get(key) if n > 0 else None
+    if cached is not None:
+        tiles, expected = cached
+    else:
+        counts_dev = got[:, :8].contiguous().view(torch.int64).flatten()
+        tiles, expected = [int(v) for v in counts_dev.tolist()], None      # (the one early host read: only the first pass is queued)
+        if min(tiles) > 0:
+            _TILE_COUNTS[key] = (tiles, counts_dev.clone())
+    if min(tiles) <= 0:
+        raise ValueError(f"every rank needs at least one tile for a pooled statistic, got tiles per rank {tiles} (shard with shard_bounds over >= world_size tiles)")
+    n_all = int(sum(tiles)) * h * w
+    if n_all >= 1 << 32:
+        raise ValueError(f"a pooled fit over {n_all} pixels exceeds the 2^32 the native counters hold; fit on a subset of the tiles")
+    counts = [steps.pfit_sample_count(int(tiles[r]), h, w) for r in range(size)]
+    sample_count = min(4096, sum((c + size - 1) // size for c in counts))
+    stale = steps.pfit_plane_packed(got, counts, expected, n_all, sample_count, shape)
+    share = int(_share) if _share else 32768 // size
+    out = None
+    for stage in (0, 1):
+        sums = all_reduce_sum(steps.pfit_pass(local_images, stage, n_all, sample_count), group)
+        rows = all_gather_stack(steps.pfit_gather_packed(sums, stage, n_all, sample_count, shape, share, stale), group)
+        out = steps.pfit_finish_packed(rows, stage, n_all, sample_count, shape, share)
     return out
 
 

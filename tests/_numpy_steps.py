@@ -199,6 +199,57 @@ class NumpyMacenkoBracketSteps(NumpyMacenkoSteps):
         return torch.from_numpy(st["he"].copy()), torch.from_numpy(max_c), torch.full((1,), 1 if st.get("missed") else 0, dtype=torch.int32)
 
 
+class NumpyMacenkoPackedSteps(NumpyMacenkoBracketSteps):
+    """The same steps behind the PACKED interface (include/stainx_hip.h, sx_macenko_pfit_*_packed): one contiguous record per rank and
+    exchange, packed and unpacked here the way the library's kernels do it -- so the gloo tests run the choreography the product runs."""
+    RECORD = 8 + 80 + 3 * 4096 * 4
+
+    def pfit_stats_packed(self, images):
+        mom, sample = self.pfit_stats(images)
+        rec = np.zeros(self.RECORD, dtype=np.uint8)
+        rec[:8] = np.array([images.shape[0]], dtype=np.int64).view(np.uint8)
+        rec[8:88] = np.asarray(mom.numpy(), dtype=np.float64).view(np.uint8)
+        rec[88:] = np.ascontiguousarray(sample.numpy(), dtype=np.float32).reshape(-1).view(np.uint8)
+        return torch.from_numpy(rec)
+
+    def pfit_empty_record(self):
+        return torch.zeros(self.RECORD, dtype=torch.uint8)
+
+    def pfit_plane_packed(self, gathered, sample_counts, expected_tiles, n_all, sample_count, shape):
+        got = gathered.numpy()
+        world = got.shape[0]
+        tiles = np.array([got[r, :8].copy().view(np.int64)[0] for r in range(world)])
+        moments = np.zeros(10, dtype=np.float64)
+        for r in range(world):                                    # rank order, like the kernel
+            moments = moments + got[r, 8:88].copy().view(np.float64)
+        union = np.zeros((3, 4096), dtype=np.float32)
+        base = 0
+        for r in range(world):
+            sample = got[r, 88:].copy().view(np.float32).reshape(3, 4096)
+            cols = sample[:, : int(sample_counts[r]) : world]
+            take = min(cols.shape[1], 4096 - base)
+            if take > 0:
+                union[:, base: base + take] = cols[:, :take]
+            base += cols.shape[1]
+        assert min(base, 4096) == sample_count, (base, sample_count)
+        self.pfit_plane(torch.from_numpy(moments), n_all, torch.from_numpy(union), sample_count, shape)
+        stale = 0 if expected_tiles is None else int((tiles != expected_tiles.numpy()).any())
+        return torch.tensor([stale], dtype=torch.int32)
+
+    def pfit_gather_packed(self, sums_global, stage, n_all, sample_count, shape, share, stale):
+        compact, counts = self.pfit_gather(sums_global, stage, n_all, sample_count, shape, share)
+        flag = torch.zeros(1, dtype=torch.int32) if stale is None else stale.to(torch.int32).reshape(1)
+        return torch.cat([counts.to(torch.int32).flatten(), flag, compact.to(torch.int32).flatten()])
+
+    def pfit_finish_packed(self, gathered_rows, stage, n_all, sample_count, shape, share):
+        world = gathered_rows.shape[0]
+        out = self.pfit_finish(gathered_rows[:, 3:].reshape(world, 2, share), gathered_rows[:, :2], stage, n_all, sample_count, shape)
+        if out is None:
+            return None
+        he, max_c, status = out
+        return he, max_c, status + 16 * int(gathered_rows[:, 2].max())
+
+
 def keys_to_float(keys: np.ndarray) -> np.ndarray:
     k = np.ascontiguousarray(keys, dtype=np.uint32)
     u = np.where(k >> 31 != 0, k & np.uint32(0x7FFFFFFF), ~k)

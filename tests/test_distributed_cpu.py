@@ -23,7 +23,7 @@ def _free_port() -> int:
 
 
 def _worker(rank: int, world_size: int, port: int, out_dir: str):
-    from tests._numpy_steps import NumpyHMSteps, NumpyMacenkoBracketSteps, NumpyMacenkoSteps, NumpyReinhardSteps
+    from tests._numpy_steps import NumpyHMSteps, NumpyMacenkoBracketSteps, NumpyMacenkoPackedSteps, NumpyMacenkoSteps, NumpyReinhardSteps
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
@@ -35,12 +35,15 @@ def _worker(rank: int, world_size: int, port: int, out_dir: str):
         bracket_steps = NumpyMacenkoBracketSteps()
         he_b, max_c_b = sxd.macenko_fit_pooled(local, steps=bracket_steps)                  # the bracket form (default)
         assert hasattr(bracket_steps, "state"), "the bracket choreography did not run"
+        packed_steps = NumpyMacenkoPackedSteps()
+        he_p, max_c_p = sxd.macenko_fit_pooled(local, steps=packed_steps)                   # the same with the exchanges' records packed (what the HIP steps run)
+        assert hasattr(packed_steps, "state")
         noise = synth.noise_u8((5, 3, 32, 32), 11)
         ref_mean, ref_std = so.reinhard_fit(synth.noise_u8((1, 3, 32, 32), 12).numpy())
         rein = sxd.reinhard_transform_pooled(noise[lo:hi], ref_mean, ref_std, steps=NumpyReinhardSteps())
         hists = so.hm_fit(synth.noise_u8((1, 3, 32, 32), 12).numpy())
         hm = sxd.hm_transform_pooled(noise[lo:hi], hists, steps=NumpyHMSteps())
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), he=he.numpy(), max_c=max_c.numpy(), he_b=he_b.numpy(), max_c_b=max_c_b.numpy(), rein=rein.numpy(), hm=hm.numpy(), lo=lo, hi=hi)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), he=he.numpy(), max_c=max_c.numpy(), he_b=he_b.numpy(), max_c_b=max_c_b.numpy(), he_p=he_p.numpy(), max_c_p=max_c_p.numpy(), rein=rein.numpy(), hm=hm.numpy(), lo=lo, hi=hi)
     finally:
         dist.destroy_process_group()
 
@@ -66,6 +69,8 @@ def test_two_rank_gloo_matches_single_process_oracle(tmp_path):
     for r in (r0, r1):                                                   # bracket form: same answer, same bits on both ranks
         np.testing.assert_array_equal(r["he_b"], r["he"])
         np.testing.assert_array_equal(r["max_c_b"], r["max_c"])
+        np.testing.assert_array_equal(r["he_p"], r["he"])                # packed records: the same bits again
+        np.testing.assert_array_equal(r["max_c_p"], r["max_c"])
     np.testing.assert_array_equal(r0["max_c"], r1["max_c"])
     assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 3, 3, 5)
     noise = synth.noise_u8((5, 3, 32, 32), 11).numpy()
@@ -80,7 +85,7 @@ def test_two_rank_gloo_matches_single_process_oracle(tmp_path):
 
 
 def _empty_rank_worker(rank: int, world_size: int, port: int, out_dir: str):
-    from tests._numpy_steps import NumpyHMSteps, NumpyMacenkoBracketSteps
+    from tests._numpy_steps import NumpyHMSteps, NumpyMacenkoBracketSteps, NumpyMacenkoPackedSteps
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
@@ -89,6 +94,7 @@ def _empty_rank_worker(rank: int, world_size: int, port: int, out_dir: str):
         lo, hi = sxd.shard_bounds(1, rank, world_size)
         raised = []
         for call in (lambda: sxd.macenko_fit_pooled(tiles[lo:hi], steps=NumpyMacenkoBracketSteps()),
+                     lambda: sxd.macenko_fit_pooled(tiles[lo:hi], steps=NumpyMacenkoPackedSteps()),
                      lambda: sxd.macenko_fit_pooled(tiles[lo:hi], steps=NumpyMacenkoBracketSteps(), method="radix"),      # (the radix form skipped the guard)
                      lambda: sxd.hm_transform_pooled(synth.noise_u8((1, 3, 16, 16), 1)[lo:hi], so.hm_fit(synth.noise_u8((1, 3, 16, 16), 2).numpy()), steps=NumpyHMSteps())):
             try:
@@ -142,29 +148,31 @@ def test_forced_collectives_at_world_size_one(tmp_path):
     assert bool(np.load(tmp_path / "forced.npz")["same"])
 
 
-def _resharded_worker(rank: int, world_size: int, port: int, out_dir: str):
+def _resharded_worker(rank: int, world_size: int, port: int, out_dir: str, packed: bool):
     """Two calls with the same local shape on rank 0 while rank 1's shard shrinks: rank 0's cached tile counts are stale in the second
     call; the flag travels with the stage exchange, so BOTH ranks repeat the fit (nobody is left alone in a collective) and the
     result is the one of the new sharding."""
-    from tests._numpy_steps import NumpyMacenkoBracketSteps
+    from tests._numpy_steps import NumpyMacenkoBracketSteps, NumpyMacenkoPackedSteps
 
+    Steps = NumpyMacenkoPackedSteps if packed else NumpyMacenkoBracketSteps
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
         sxd._TILE_COUNTS.clear()
         tiles = synth.he_batch(5, 48, 48, seed0=31)
-        first = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:5], steps=NumpyMacenkoBracketSteps())
+        first = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:5], steps=Steps())
         cached_after_first = len(sxd._TILE_COUNTS)
-        second = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:4], steps=NumpyMacenkoBracketSteps())      # rank 1: one tile now
-        third = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:4], steps=NumpyMacenkoBracketSteps())       # (cached again, and right)
+        second = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:4], steps=Steps())      # rank 1: one tile now
+        third = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:4], steps=Steps())       # (cached again, and right)
         np.savez(os.path.join(out_dir, f"reshard{rank}.npz"), he1=first[0].numpy(), he2=second[0].numpy(), mc2=second[1].numpy(), he3=third[0].numpy(), cached=cached_after_first)
     finally:
         sxd._TILE_COUNTS.clear()
         dist.destroy_process_group()
 
 
-def test_cached_tile_counts_are_checked_collectively(tmp_path):
-    mp.spawn(_resharded_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("packed", [False, True])
+def test_cached_tile_counts_are_checked_collectively(tmp_path, packed):
+    mp.spawn(_resharded_worker, args=(2, _free_port(), str(tmp_path), packed), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "reshard0.npz"), np.load(tmp_path / "reshard1.npz")
     assert int(r0["cached"]) == 1
     tiles = synth.he_batch(5, 48, 48, seed0=31)

@@ -126,7 +126,7 @@ def _rccl_worker(rank: int, world_size: int, port: int, out_dir: str):
     dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
     try:
         calls = {"all_reduce": 0, "all_gather": 0}
-        real_ar, real_ag = dist.all_reduce, dist.all_gather
+        real_ar, real_ag, real_agt = dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor
 
         def count_ar(*a, **k):
             calls["all_reduce"] += 1
@@ -136,7 +136,11 @@ def _rccl_worker(rank: int, world_size: int, port: int, out_dir: str):
             calls["all_gather"] += 1
             return real_ag(*a, **k)
 
-        dist.all_reduce, dist.all_gather = count_ar, count_ag
+        def count_agt(*a, **k):      # (device tensors are gathered straight into the stacked result)
+            calls["all_gather"] += 1
+            return real_agt(*a, **k)
+
+        dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor = count_ar, count_ag, count_agt
         from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP, MacenkoHIP, ReinhardHIP
 
         tiles = synth.he_batch(8, 128, 128).to(dev)
