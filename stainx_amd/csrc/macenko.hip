@@ -2603,7 +2603,9 @@ static void set_chunk(Geometry& g, bool may_add_item) {
     const int b0 = (int)((g.pixels + kChunk - 1) / kChunk);
     int best_b = b0;
     int64_t best_chunk = 0, best_cost = 0;
-    for (int b = b0; b <= b0 + (may_add_item && even_items_size(g.pixels) ? 1 : 0); ++b) {
+    // (narrow pixels only: float32 / float64 tiles of these sizes take the two-pass form, whose pass A holds four workgroups per CU --
+    // 1280 work items instead of 1024 are a second round there: 256 x 224 x 224 float32 163 -> 177 us)
+    for (int b = b0; b <= b0 + (may_add_item && g.vec_width >= 8 && even_items_size(g.pixels) ? 1 : 0); ++b) {
         const int64_t even = (g.pixels + b - 1) / b;
         const int64_t chunk = std::min<int64_t>(kChunk, (even + unit - 1) / unit * unit);
         if ((int64_t)(b - 1) * chunk >= g.pixels) continue;      // (the last item would be empty)

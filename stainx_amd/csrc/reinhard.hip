@@ -243,7 +243,8 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
         last = false;
         if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.blocks_per_tile - 1) {
             __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call on this workspace
-            last = __hip_atomic_fetch_add(&st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.n_tiles - 1;
+            // (one tile: its last arrival is the call's -- a fit on a reference tile is launch-bound, every dependent round trip shows)
+            last = g.n_tiles == 1 || __hip_atomic_fetch_add(&st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)g.n_tiles - 1;
         }
     }
     __syncthreads();
