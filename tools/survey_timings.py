@@ -26,14 +26,17 @@ for n, h, w in shapes:
             for unit in (False, True):
                 for _ in range(3):
                     be.transform(x, he, mc, channels_last=last, normalize_to_0_1=unit)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    be.transform(x, he, mc, channels_last=last, normalize_to_0_1=unit)
-                e1.record()
-                torch.cuda.synchronize()
-                row[("nhwc" if last else "nchw") + ("/255" if unit else "")] = round(e0.elapsed_time(e1) / 20 * 1e3, 1)      # us
+                runs = []
+                for _ in range(3):      # median of three runs (a stall of the box inside one run is not a property of the path)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        be.transform(x, he, mc, channels_last=last, normalize_to_0_1=unit)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    runs.append(e0.elapsed_time(e1) / 20 * 1e3)
+                row[("nhwc" if last else "nchw") + ("/255" if unit else "")] = round(sorted(runs)[1], 1)      # us
         vals = [v for k, v in row.items() if k not in ("shape", "dtype")]
         row["spread"] = round(max(vals) / min(vals), 2)
         print(json.dumps(row), flush=True)
