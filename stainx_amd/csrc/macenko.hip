@@ -2364,8 +2364,10 @@ __device__ void scale_stage(const T* __restrict__ images, const Geometry& g, con
 // ------------------------------------------------------------------------------------------------
 // kernels, one launch per stage
 // ------------------------------------------------------------------------------------------------
+// (two-byte pixels: five waves per SIMD -- a 224 x 224 tile is five work items (set_chunk), 1280 for the batch that matters, and at the
+// 106 registers the compiler would take, four workgroups per CU made that a second round)
 template <typename T, int V, bool kInter = false>
-__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
+__global__ __launch_bounds__(kStreamThreads, sizeof(T) <= 2 ? 5 : 1) void stats_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ StatsScratch<kStreamThreads> sh;
     __shared__ LevelTables<T> tb;
     tb.fill();
@@ -2603,8 +2605,9 @@ static void set_chunk(Geometry& g, bool may_add_item) {
     const int b0 = (int)((g.pixels + kChunk - 1) / kChunk);
     int best_b = b0;
     int64_t best_chunk = 0, best_cost = 0;
-    // (narrow pixels only: float32 / float64 tiles of these sizes take the two-pass form, whose pass A holds four workgroups per CU --
-    // 1280 work items instead of 1024 are a second round there: 256 x 224 x 224 float32 163 -> 177 us)
+    // (two-byte pixels only.  float32 / float64 tiles of these sizes take the two-pass form, whose pass A holds four workgroups per CU:
+    // 1280 work items instead of 1024 are a second round there, 256 x 224 x 224 float32 163 -> 177 us.  uint8: a pack is 16 pixels, the
+    // rounding unit 4096, and the moments pass needs 112 registers -- four workgroups per CU again; measured below)
     for (int b = b0; b <= b0 + (may_add_item && g.vec_width >= 8 && even_items_size(g.pixels) ? 1 : 0); ++b) {
         const int64_t even = (g.pixels + b - 1) / b;
         const int64_t chunk = std::min<int64_t>(kChunk, (even + unit - 1) / unit * unit);

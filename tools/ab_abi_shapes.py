@@ -20,15 +20,16 @@ def load(name):
 sm = torch.tensor(synth.HE_REF).to(dev); tmc = torch.tensor([1.9705, 1.0308]).to(dev)
 def survey(lib):
   rows = {}
-  for name, dt, shape in (("f32 256x224x224", torch.float32, (256, 224, 224)), ("bf16 256x224x224", torch.bfloat16, (256, 224, 224)), ("f32 64x512x512", torch.float32, (64, 512, 512)), ("u8 64x512x512", torch.uint8, (64, 512, 512)), ("f32 114x384x384", torch.float32, (114, 384, 384))):
+  for name, dt, shape in (("f32 256x224x224", torch.float32, (256, 224, 224)), ("bf16 256x224x224", torch.bfloat16, (256, 224, 224)), ("u8 256x224x224", torch.uint8, (256, 224, 224)), ("f32 64x512x512", torch.float32, (64, 512, 512)), ("u8 64x512x512", torch.uint8, (64, 512, 512)), ("f32 114x384x384", torch.float32, (114, 384, 384)), ("u8 64x512x512 four-pass", torch.uint8, (64, 512, 512)), ("bf16 64x512x512 four-pass", torch.bfloat16, (64, 512, 512))):
       n, h, w = shape
       x = synth.as_dtype(synth.he_batch(n, h, w), dt).to(dev)
       out = torch.empty_like(x)
       nb = int(lib.sx_macenko_workspace_bytes(n, h, w))
       ws = torch.empty(nb, dtype=torch.uint8, device=dev)
       code = _native.DTYPE_CODES[dt]
+      flags = _native.MACENKO_CLASSIC if name.endswith("four-pass") else 0
       def call():
-          rc = lib.sx_macenko_transform(x.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(), 0, ws.data_ptr(), ws.numel(), _native.stream_ptr(dev))
+          rc = lib.sx_macenko_transform(x.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(), flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(dev))
           assert rc == 0
       for _ in range(20): call()
       torch.cuda.synchronize()
