@@ -172,38 +172,38 @@ __device__ __forceinline__ float wave_total_f32(float x) {      // fixed order; 
 
 // The presample: unit u is one sector (16 consecutive pixels) of cell u at a hashed offset; four lanes per sector, so a
 // thread's share of sweep s is one quad of 4 pixels.
+// (fetch and conversion apart: the first look requests the quads of ALL its sweeps before it converts the first -- one round trip to
+// memory instead of four one after the other, 6.4 -> ~3 us of the prior launch)
 template <typename T, bool kVec, bool kInter>
-__device__ __forceinline__ bool prior_load(const T* __restrict__ img, const Geometry& g, int s, float (&od)[4][3]) {
+__device__ __forceinline__ bool prior_fetch(const T* __restrict__ img, const Geometry& g, int s, float (&u)[3][4]) {
     const int tid = threadIdx.x, unit = s * (kGroupThreads / 4) + (tid >> 2);
     const bool have = unit < g.prior_units;
-    float u[3][4];
+    // cell u = sectors [u step, (u + 1) step) in 16.16 fixed point (no integer divisions here: they cost the two looks ~2 us each)
+    const uint64_t step = (uint64_t)g.prior_step_q16;
+    const uint32_t start = (uint32_t)(((uint64_t)unit * step) >> 16), width = (uint32_t)(((uint64_t)(unit + 1) * step) >> 16) - start;
+    const uint32_t sector = start + (((((uint32_t)unit * 0x9E3779B1u) >> 16) * width) >> 16);
+    // (a thread without a unit reads the tile's first quad and drops it -- `have` gates every use: a load inside `if (have)` is a
+    // branch the next sweep's loads cannot be moved across)
+    const int64_t p = have ? ((int64_t)sector * 4 + (tid & 3)) * 4 : (int64_t)(tid & 3) * 4;
+    if constexpr (kVec) {
+        load_pixels<T, 4, kInter>(img, g.pixels, p, u);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < 4; ++i) {
+            float v[3][1];
+            load_pixels<T, 1, kInter>(img, g.pixels, p + i, v);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[c][i] = 0.0f;
-    if (have) {
-        // cell u = sectors [u step, (u + 1) step) in 16.16 fixed point (no integer divisions here: they cost the two looks ~2 us each)
-        const uint64_t step = (uint64_t)g.prior_step_q16;
-        const uint32_t start = (uint32_t)(((uint64_t)unit * step) >> 16), width = (uint32_t)(((uint64_t)(unit + 1) * step) >> 16) - start;
-        const uint32_t sector = start + (((((uint32_t)unit * 0x9E3779B1u) >> 16) * width) >> 16);
-        const int64_t p = ((int64_t)sector * 4 + (tid & 3)) * 4;
-        if constexpr (kVec) {
-            load_pixels<T, 4, kInter>(img, g.pixels, p, u);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v[3][1];
-                load_pixels<T, 1, kInter>(img, g.pixels, p + i, v);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) u[c][i] = v[c][0];
-            }
+            for (int c = 0; c < 3; ++c) u[c][i] = v[c][0];
         }
     }
+    return have;
+}
+template <typename T>
+__device__ __forceinline__ void prior_densities(const float (&u)[3][4], float (&od)[4][3]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int c = 0; c < 3; ++c) od[i][c] = optical_density<T>(u[c][i]);
-    return have;
 }
 
 template <typename T, bool kVec, bool kInter>
@@ -238,10 +238,15 @@ __global__ __launch_bounds__(kGroupThreads) void prior_kernel(const T* __restric
         float m[kPartial];
 #pragma unroll
         for (int k = 0; k < kPartial; ++k) m[k] = 0.0f;
+        float raw[kPriorSweeps][3][4];
+        bool have_quad[kPriorSweeps];
+#pragma unroll
+        for (int s = 0; s < kPriorSweeps; ++s) have_quad[s] = prior_fetch<T, kVec, kInter>(img, g, s, raw[s]);
 #pragma unroll
         for (int s = 0; s < kPriorSweeps; ++s) {
             float od[4][3];
-            const bool have = prior_load<T, kVec, kInter>(img, g, s, od);
+            prior_densities<T>(raw[s], od);
+            const bool have = have_quad[s];
             // (kept for the second look in fp16: brackets and thresholds of a SAMPLE need no more, and reading the pixels again
             // -- from L2, with their logarithms -- was 3 us of this kernel)
 #pragma unroll
