@@ -143,3 +143,36 @@ def test_exported_angle_percentiles_match_the_reference(dev, golden):
             for i in range(src.shape[0]):
                 lo, hi = mapped(float(g1[f"{name}_phi_lo"][i]), float(g1[f"{name}_phi_hi"][i]), g1[f"{name}_vecs"][i], p["vecs"][i].numpy())
                 assert abs(float(p["phi_lo"][i]) - lo) <= 2e-4 and abs(float(p["phi_hi"][i]) - hi) <= 2e-4, (size, name, i)
+
+
+def test_reinhard_full_size_against_the_oracle_and_its_own_statistics(dev):
+    """Reinhard at 64 x 3 x 512 x 512 float32 (the shape of the sibling bench): (1) the pooled source statistics against the
+    oracle's on the same 16.7 M pixels; (2) the first and last tiles of the output against the oracle's transform with those
+    statistics (1e-4 on [0, 1]); (3) a property no size can hide: the LAB statistics of the OUTPUT are the target's (the
+    normalisation is affine in LAB; what the [0, 1] clamp cuts off is a fraction of a LAB unit on this data); (4) the batch is
+    one pooled population: a permutation of the tiles permutes the output and nothing else (sums in another order: last bits)."""
+    from stainx_amd.backends.torch_hip_backend import ReinhardHIP
+
+    be = ReinhardHIP(dev)
+    src = synth.as_dtype(synth.he_batch(64, 512, 512, seed0=900), torch.float32)
+    ref = synth.as_dtype(synth.he_batch(1, 512, 512, seed0=77), torch.float32)
+    x = src.to(dev)
+    ref_mean, ref_std = be.compute_reference_mean_std(ref.to(dev))
+    src_mean, src_std = be.compute_reference_mean_std(x)
+    want_mean, want_std = so.reinhard_fit(src.numpy())
+    np.testing.assert_allclose(src_mean.cpu().numpy(), want_mean, rtol=0, atol=2e-3)          # LAB units (0..255)
+    np.testing.assert_allclose(src_std.cpu().numpy(), want_std, rtol=1e-4, atol=1e-3)
+    out = be.transform(x, ref_mean, ref_std)
+    assert out.dtype == torch.float32 and out.shape == x.shape and bool(torch.isfinite(out).all())
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    lab = so.rgb_to_lab(so.to_unit_float(src.numpy()[[0, 63]]))
+    mean64, std64 = src_mean.cpu().numpy().astype(np.float32), src_std.cpu().numpy().astype(np.float32)
+    lab = (lab - mean64[None, :, None, None]) / (std64[None, :, None, None] + np.float32(1e-8)) * ref_std.cpu().numpy()[None, :, None, None] + ref_mean.cpu().numpy()[None, :, None, None]
+    want = np.clip(so.lab_to_rgb(lab.astype(np.float32)), 0.0, 1.0)
+    assert np.abs(out[[0, 63]].cpu().numpy() - want).max() <= 1e-4
+    out_mean, out_std = be.compute_reference_mean_std(out)
+    np.testing.assert_allclose(out_mean.cpu().numpy(), ref_mean.cpu().numpy(), rtol=0, atol=0.5)
+    np.testing.assert_allclose(out_std.cpu().numpy(), ref_std.cpu().numpy(), rtol=0.03, atol=0.1)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(5))
+    out_p = be.transform(x[perm.to(dev)].contiguous(), ref_mean, ref_std)
+    assert float((out_p - out[perm.to(dev)]).abs().max()) <= 2e-6
