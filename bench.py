@@ -256,12 +256,18 @@ def main() -> None:
         os.environ["STAINX_FORCE_COLLECTIVES"] = "1"
     distributed = world > 1 or pooled or bool(os.environ.get("STAINX_BENCH_FORCE_DIST"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # STAINX_BENCH_REHEARSE=1: several ranks on ONE GPU with gloo for the barrier and the max over ranks -- a rehearsal of the
+    # N > 1 code path (rank handling, aggregation, who prints) on a one-GPU box; RCCL refuses two ranks on one device.  Not a measurement.
+    rehearse = bool(os.environ.get("STAINX_BENCH_REHEARSE")) and not pooled
+    device_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if distributed:
         import torch.distributed as dist
 
-        if world == 1:
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        elif world == 1:
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -282,7 +288,7 @@ def main() -> None:
         torch.cuda.synchronize(dev)
 
     def max_over_ranks(seconds: float) -> float:
-        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if rehearse else dev)
         if distributed:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -388,6 +394,8 @@ def main() -> None:
                                              "note": f"the only launch that moves the full 24 B/px; its rocprofv3 average is in {KERNEL_STATS}"}},
             "kernel_source_hash": source_hash(),
         }
+        if os.environ.get("STAINX_BENCH_REHEARSE"):
+            line["rehearsal"] = "ranks share ONE GPU (gloo for the barrier and the max): a run of the N > 1 code path, not a measurement"
         if world == 1 and not args.no_cpu:
             he = norm._stain_matrix.cpu().numpy()
             max_c = norm._target_max_conc.cpu().numpy()
