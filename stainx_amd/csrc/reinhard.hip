@@ -380,6 +380,8 @@ __global__ void finalize_kernel(const double* __restrict__ sums, double n, State
     st->stdv[c] = (float)((double)lab_scale(c) * sqrt(fmax(var, 0.0)));
 }
 
+static std::atomic<unsigned int> g_calls{0};      // numbers the calls (of every element type) for the ready-state check, see State
+
 template <typename T>
 static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, float* mean_out, float* std_out, double* sums_out, const double* sums_in, double n_total, void* ws, hipStream_t stream, bool ready) {
     Geometry g{n, h * w, blocks_for(h * w), kStreamThreads * 4 * kIters};
@@ -393,9 +395,8 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, c
     if (sums_in) {            // statistics come from outside (all-reduced over ranks)
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, sums_in, n_total, st);
     } else {
-        static std::atomic<unsigned int> calls{0};
-        call = ++calls;
-        if (call == 0) call = ++calls;      // (0 means "no check" to the apply pass)
+        call = ++g_calls;
+        if (call == 0) call = ++g_calls;      // (0 means "no check" to the apply pass)
         if (!ready) hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, tile_arrivals, n);
         if (vec)
             hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, tile_arrivals, mean_out, std_out, sums_out, call);
