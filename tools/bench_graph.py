@@ -1,15 +1,17 @@
-"""Does a HIP graph shorten the call?  The two-pass transform (4 launches) eager vs replayed from a captured graph.
-    python tools/bench_graph.py"""
+"""Does a HIP graph shorten the call?  The transform eager vs replayed from a captured graph: the two-pass form (4 launches) on
+64 x 512 x 512, or the default form of any N H W given (small batches: seven launches of the four-pass form).
+    python tools/bench_graph.py [N H W]"""
 import sys, json, torch
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
 from stainx_amd import synth, _native
 from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
 dev = torch.device("cuda:0")
-x = synth.as_dtype(synth.he_batch(64, 512, 512), torch.float32).to(dev)
+shape = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (64, 512, 512)
+x = synth.as_dtype(synth.he_batch(*shape), torch.float32).to(dev)
 be = MacenkoHIP(dev)
 sm = torch.tensor(synth.HE_REF).to(dev); tmc = torch.tensor([1.9705, 1.0308]).to(dev)
-F = _native.MACENKO_TWO_PASS
+F = _native.MACENKO_TWO_PASS if len(sys.argv) < 4 else _native.MACENKO_CLASSIC
 
 def timed(fn, steps=300, warm=30):
     for _ in range(warm): fn()
@@ -30,4 +32,4 @@ with torch.cuda.graph(g, stream=s):
     out = be.transform(x, sm, tmc, _extra_flags=F)
 graph = timed(g.replay)
 ref = be.transform(x, sm, tmc, _extra_flags=F)
-print(json.dumps({"eager_us": round(eager, 1), "graph_replay_us": round(graph, 1), "same_bits": bool(torch.equal(ref.view(torch.uint8), out.view(torch.uint8)))}))
+print(json.dumps({"shape": list(shape), "eager_us": round(eager, 1), "graph_replay_us": round(graph, 1), "same_bits": bool(torch.equal(ref.view(torch.uint8), out.view(torch.uint8)))}))
