@@ -354,11 +354,19 @@ __global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restri
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-static int blocks_for(int64_t pixels) {
-    const int64_t chunk = (int64_t)kStreamThreads * 4 * kIters;
+// Sweeps of a workgroup per work item: eight on a batch that fills the chip (64 tiles of 512 x 512: 2048 work items), fewer on small
+// ones -- a single 512 x 512 tile is 32 work items at eight sweeps and two launches that last as long as ONE of them; at one sweep
+// it is 256 (fit + transform of BASELINE configs[0]: 52 -> see DESIGN.md section 5).  A function of the batch's shape only.
+static int sweeps_for(int64_t n, int64_t pixels) {
+    int sweeps = kIters;
+    while (sweeps > 1 && n * ((pixels + (int64_t)kStreamThreads * 4 * sweeps - 1) / ((int64_t)kStreamThreads * 4 * sweeps)) < 512) sweeps /= 2;
+    return sweeps;
+}
+static int blocks_for(int64_t n, int64_t pixels) {
+    const int64_t chunk = (int64_t)kStreamThreads * 4 * sweeps_for(n, pixels);
     return (int)((pixels + chunk - 1) / chunk);
 }
-static size_t partial_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(double) * kSums * (size_t)blocks_for(pixels) * (size_t)n, 256); }
+static size_t partial_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(double) * kSums * (size_t)blocks_for(n, pixels) * (size_t)n, 256); }
 static size_t workspace_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(State), 256) + partial_bytes(n, pixels) + align_up(sizeof(unsigned int) * kTileCounterStride * (size_t)n, 256); }
 
 __global__ void init_state_kernel(State* st, unsigned int* tile_arrivals, int64_t n_tiles) {
@@ -384,7 +392,7 @@ static std::atomic<unsigned int> g_calls{0};      // numbers the calls (of every
 
 template <typename T>
 static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, float* mean_out, float* std_out, double* sums_out, const double* sums_in, double n_total, void* ws, hipStream_t stream, bool ready) {
-    Geometry g{n, h * w, blocks_for(h * w), kStreamThreads * 4 * kIters};
+    Geometry g{n, h * w, blocks_for(n, h * w), kStreamThreads * 4 * sweeps_for(n, h * w)};
     State* st = static_cast<State*>(ws);
     double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + align_up(sizeof(State), 256));
     unsigned int* tile_arrivals = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(partial) + partial_bytes(n, h * w));
