@@ -59,6 +59,8 @@ typedef enum {
                                        measured slower than the four launches on MI355X; kept for A/B runs and tests */
 #define SX_MACENKO_SPEC_FAIL 128u    /* diagnostic: the two-pass form treats every speculation as failed (forces its slow exact path; tests) */
 #define SX_MACENKO_NO_TIE_SHORTCUT 8u /* diagnostic: do not resolve a bracket that closed on one key from its counts (forces the slow exact paths; tests) */
+#define SX_MACENKO_RESIDENT 1024u    /* the tile-resident form (one launch; pixels kept on chip as 8-bit codes) wherever it can run -- by default only where it
+                                        has been measured to be the faster one; tests, A/B runs */
 #define SX_MACENKO_CHANNELS_LAST 2u /* images and output are (N,H,W,3) (decoder / PIL layout) instead of (N,3,H,W); an extension: the
                                       reference takes NCHW only and callers permute + copy first */
 

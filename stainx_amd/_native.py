@@ -27,6 +27,7 @@ MACENKO_OUT_F16 = 64
 MACENKO_SPEC_FAIL = 128
 MACENKO_TWO_PASS = 256
 MACENKO_FUSE = 512
+MACENKO_RESIDENT = 1024
 MACENKO_PARAM_FLOATS = 48
 PFIT_STATS_RECORD_BYTES = 49240
 PFIT_SUMS = 1033

@@ -2596,6 +2596,7 @@ __global__ void export_params_kernel(const GroupState* __restrict__ state, int64
 }  // namespace sx
 #include "macenko_twopass.hpp"
 #include "macenko_fused.hpp"
+#include "macenko_resident.hpp"
 namespace sx {
 namespace macenko {
 static_assert(sizeof(PriorRecord) == kPriorRecordBytes, "workspace layout");
@@ -2750,6 +2751,77 @@ static int run_transform(const T* images, O* out, const Geometry& g, const Works
     else
         hipLaunchKernelGGL((reconstruct_kernel<T, O, VR, false, kInter>), dim3(items_r), dim3(kStreamThreads), 0, stream, images, out, gr, ws, sm);
     return check_launch("macenko reconstruct");
+}
+
+// ---- the tile-resident form (macenko_resident.hpp) ---------------------------------------------------------------------------
+// Compute units of the current device (the launch must be resident at once: one 1024-thread workgroup per CU); 256 when no device
+// can be asked (workspace sizing on a host without one).
+static int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+static int elem_bytes(int dtype) { return dtype == SX_U8 ? 1 : (dtype == SX_F16 || dtype == SX_BF16) ? 2 : dtype == SX_F32 ? 4 : 8; }
+// Whether a call can take the resident form at all: planar tiles of whole 16-byte packs, one to sixteen workgroups per tile,
+// the output of the input's type (uint8 with normalize_to_0_1: float32).
+static bool resident_able(int dtype, int64_t n, int64_t pixels, unsigned flags) {
+    if (dtype != SX_U8 && dtype != SX_F16 && dtype != SX_BF16 && dtype != SX_F32) return false;
+    if (flags & (SX_MACENKO_SAMPLED | SX_MACENKO_CHANNELS_LAST | SX_MACENKO_OUT_BF16 | SX_MACENKO_OUT_F16)) return false;
+    const int64_t pack = 16 / elem_bytes(dtype);
+    if (pixels % pack != 0 || pixels < 1024) return false;
+    const int64_t items = (pixels + kChunk - 1) / kChunk, group = (items + kResQuads - 1) / kResQuads;
+    return group <= kResMaxGroup && group <= device_cus() && n >= 1;
+}
+static ResGeom resident_geometry(int dtype, int64_t n, int64_t pixels, bool unit) {
+    Geometry g = make_geometry(n, pixels, 0);
+    g.vec = 1;
+    g.vec_width = 16 / elem_bytes(dtype);
+    set_chunk(g, false);
+    ResGeom rg{};
+    rg.n_tiles = n;
+    rg.pixels = pixels;
+    rg.items = g.blocks_per_tile;
+    rg.chunk = g.chunk;
+    rg.group = (rg.items + kResQuads - 1) / kResQuads;
+    const int cus = device_cus();
+    int fit = std::max(cus / rg.group, 1);      // tiles whose workgroups are resident together
+    if (fit >= 8 && n >= 8) {
+        fit = fit / 8 * 8;
+        rg.tiles_per_round = (int)std::min<int64_t>((n + 7) / 8 * 8, fit);
+        rg.xcd_map = 1;
+    } else {
+        rg.tiles_per_round = (int)std::min<int64_t>(n, fit);
+        rg.xcd_map = 0;
+    }
+    rg.rounds = (int)((n + rg.tiles_per_round - 1) / rg.tiles_per_round);
+    rg.unit = unit ? 1 : 0;
+    rg.spin_limit = 1u << 22;      // (seconds)
+    return rg;
+}
+template <typename T, typename O>
+static int run_resident(const void* images, void* out, const ResGeom& rg, const ResWork& rw, const float* sm, const float* tmc, hipStream_t stream) {
+    constexpr int W = PackOf<T>::n;
+    if (rg.group > 1 && hipMemsetAsync(rw.sync, 0, sizeof(ResSync) * (size_t)rg.n_tiles, stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "macenko resident: clearing the arrival counters failed");
+    const unsigned grid = (unsigned)(rg.tiles_per_round * rg.group);
+    hipLaunchKernelGGL((resident_kernel<T, O, W>), dim3(grid), dim3(kResThreads), 0, stream, static_cast<const T*>(images), static_cast<O*>(out), rg, rw, sm, tmc);
+    return check_launch("macenko resident transform");
+}
+static int resident_transform(const void* images, void* out, int dtype, int64_t n, int64_t pixels, void* ws_ptr, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
+    const ResGeom rg = resident_geometry(dtype, n, pixels, unit);
+    const ResWork rw = carve_resident(ws_ptr, n, pixels);
+    switch (dtype) {
+        case SX_U8: return unit ? run_resident<uint8_t, float>(images, out, rg, rw, sm, tmc, stream) : run_resident<uint8_t, uint8_t>(images, out, rg, rw, sm, tmc, stream);
+        case SX_F16: return run_resident<__half, __half>(images, out, rg, rw, sm, tmc, stream);
+        case SX_BF16: return run_resident<__hip_bfloat16, __hip_bfloat16>(images, out, rg, rw, sm, tmc, stream);
+        case SX_F32: return run_resident<float, float>(images, out, rg, rw, sm, tmc, stream);
+        default: return fail(SX_ERR_DTYPE, "the resident form takes uint8 / float16 / bfloat16 / float32 tiles");
+    }
 }
 
 template <typename T>
@@ -3125,7 +3197,7 @@ static int validate_images(const void* images, int64_t n, int64_t h, int64_t w, 
 
 extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, int64_t width) {
     if (n_tiles <= 0 || height <= 0 || width <= 0) return 0;
-    return macenko::workspace_bytes(n_tiles, height * width);
+    return std::max(macenko::workspace_bytes(n_tiles, height * width), macenko::resident_bytes(n_tiles, height * width));
 }
 
 // Which form sx_macenko_transform takes for a call: 0 the four passes, 1 the two-pass form as four launches, 2 the two-pass form
@@ -3138,6 +3210,10 @@ extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, in
 extern "C" int sx_macenko_form(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) {
     if (n <= 0 || h <= 0 || w <= 0 || (flags & SX_MACENKO_SAMPLED)) return 0;
     const int64_t pixels = h * w;
+    // 3: the tile-resident form (macenko_resident.hpp) -- asked for (SX_MACENKO_RESIDENT), or by default where it pays
+    if (!(flags & (SX_MACENKO_CLASSIC | SX_MACENKO_TWO_PASS | SX_MACENKO_FUSE)) && resident_able(dtype, n, pixels, flags)) {
+        if ((flags & SX_MACENKO_RESIDENT) != 0) return 3;      // (opt-in: measured slower than the multi-launch forms so far -- DESIGN.md section 4e)
+    }
     // (narrow pixels -- uint8 / f16 / bf16 -- since the candidates travel as dense records: tiles of ~360 x 360 ... 512 x 512, where the
     // two-pass form saves two instruction-bound passes -- uint8 64 x 512 x 512: 106 us against 118, bf16 126 against 144; at 320 x 320 and
     // below, and on the per-wave segments of larger tiles, the four passes win: tools/bench_twopass.py, profiles/r03_forms_by_dtype_and_tile.jsonl)
@@ -3148,7 +3224,7 @@ extern "C" int sx_macenko_form(int dtype, int64_t n, int64_t h, int64_t w, unsig
     const bool fusable = (flags & SX_MACENKO_FUSE) != 0 && dtype == SX_F32 && fused_size(pixels) && !(flags & SX_MACENKO_CHANNELS_LAST);
     return fusable ? 2 : 1;
 }
-extern "C" int sx_macenko_takes_two_pass(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) { return sx_macenko_form(dtype, n, h, w, flags) != 0 ? 1 : 0; }
+extern "C" int sx_macenko_takes_two_pass(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) { const int f = sx_macenko_form(dtype, n, h, w, flags); return (f == 1 || f == 2) ? 1 : 0; }
 
 // The part of the workspace ONE call of sx_macenko_transform with these arguments needs (a prefix of sx_macenko_workspace_bytes(),
 // which serves any call): without the two-pass areas where the call takes the four-pass form (narrow pixels, small batches), and
@@ -3156,6 +3232,8 @@ extern "C" int sx_macenko_takes_two_pass(int dtype, int64_t n, int64_t h, int64_
 extern "C" size_t sx_macenko_workspace_bytes_for(int dtype, int64_t n_tiles, int64_t height, int64_t width, unsigned flags) {
     if (n_tiles <= 0 || height <= 0 || width <= 0) return 0;
     const int form = sx_macenko_form(dtype, n_tiles, height, width, flags);
+    // (the resident form's buffer also serves the four passes: a call whose pointers turn out not to be 16-byte aligned takes those)
+    if (form == 3) return std::max(macenko::resident_bytes(n_tiles, height * width), macenko::workspace_bytes(n_tiles, height * width, kWsBase));
     // (the four-launch two-pass form keeps its candidates in the dense record arrays too for tiles up to 512 x 512: only larger
     // tiles need the per-wave segments)
     const bool dense = form != 0 && fused_size(height * width);
@@ -3174,12 +3252,16 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     g.no_tie = (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0;
     g.out_code = (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0);
     g.spec_fail = (flags & SX_MACENKO_SPEC_FAIL) ? 1 : 0;
-    const int form = sx_macenko_form(dtype, n, h, w, flags);
+    int form = sx_macenko_form(dtype, n, h, w, flags);
+    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
+    const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
+    if (form == 3) {
+        if (aligned_for(images, 16) && aligned_for(out, 16)) return resident_transform(images, out, dtype, n, h * w, ws_ptr, sm, tmc, unit, stream);
+        form = 0;
+    }
     g.two_pass = form != 0 ? 1 : 0;
     g.fused = form == 2 ? 1 : 0;
     const Workspace ws = carve(ws_ptr, n, g.pixels);
-    hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
-    const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
     switch (dtype) {
         case SX_U8: return transform_typed<uint8_t>(images, out, g, ws, sm, tmc, unit, stream);
         case SX_F16: return transform_typed<__half>(images, out, g, ws, sm, tmc, unit, stream);
