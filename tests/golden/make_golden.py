@@ -389,6 +389,31 @@ def g11_real_tissue():
     print("g11 done")
 
 
+def g12_config4_pooled_fit():
+    """BASELINE configs[3] sizes: the REAL reference's pooled fit (compute_reference_stain_matrix_torch, torch_backend.py:463-519) on the
+    64 tiles one rank holds in `bench.py --workload fit_transform_pooled` (float32 and uint8) and on all eight ranks' 512 tiles.
+    Eight floats and a count per case."""
+    blob = {}
+
+    def fit(tag, tiles):
+        m = stainx.Macenko(device="cpu", backend="torch")
+        with Capture() as cap:
+            m.fit(tiles)
+        blob[f"{tag}_he"] = to_np(m._stain_matrix)
+        blob[f"{tag}_max_c"] = to_np(m._target_max_conc)
+        blob[f"{tag}_n_kept"] = cap.stacked()["n_kept"]
+        blob[f"{tag}_sha"] = np.array(sha(tiles))
+        print(tag, blob[f"{tag}_he"].ravel(), blob[f"{tag}_max_c"], blob[f"{tag}_n_kept"], flush=True)
+
+    rank0 = synth.he_batch(64, 512, 512)
+    fit("rank0_u8", rank0)
+    fit("rank0_f32", synth.as_dtype(rank0, torch.float32))
+    world = torch.cat([synth.he_batch(64, 512, 512, seed0=1000 + 64 * r) for r in range(8)], dim=0)      # bench.py: rank r holds seed0 = 1000 + 64 r
+    fit("world8_u8", world)
+    np.savez_compressed(HERE / "g12_config4_pooled_fit.npz", **blob)
+    print("g12 done")
+
+
 def g9_histogram_matching_random():
     """80 random small cases (uniform noise, odd sizes, four dtypes): the reference's float32 LUT arithmetic depends on
     the last bit of a `sum()` whose order is ATen's vectorised one -- these cases pin it (a restatement that adds the 256
@@ -406,9 +431,9 @@ def g9_histogram_matching_random():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11", "g12"]
     table = {"g1": g1_macenko_small, "g2": g2_macenko_config2, "g3": g3_macenko_fit, "g4": g4_reinhard,
              "g5": g5_histogram_matching, "g6": g6_edge_cases, "g8": g8_transform_module, "g9": g9_histogram_matching_random,
-             "g10": g10_config5_tile_shape, "g11": g11_real_tissue}
+             "g10": g10_config5_tile_shape, "g11": g11_real_tissue, "g12": g12_config4_pooled_fit}
     for w in which:
         table[w]()

@@ -14,6 +14,7 @@ import torch.multiprocessing as mp
 from oracle import stain_oracle as so
 from stainx_amd import distributed as sxd
 from stainx_amd import synth
+from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -223,6 +224,10 @@ def test_config4_per_rank_size_against_the_oracle(tmp_path):
     he_o, mc_o = so.macenko_fit(x, signs="positive_sum")
     np.testing.assert_allclose(r["he"], he_o, rtol=0, atol=5e-5)
     np.testing.assert_allclose(r["max_c"], mc_o, rtol=1e-4, atol=0)
+    # ... and against the REAL reference's pooled fit on these very tiles (tests/golden/g12: made with stainx 0.1.4, backend="torch")
+    g12 = load_golden("g12_config4_pooled_fit.npz")
+    np.testing.assert_allclose(r["he"], g12["rank0_f32_he"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(r["max_c"], g12["rank0_f32_max_c"], rtol=1e-4, atol=0)
     np.testing.assert_array_equal(r["he"], r["he_f"])                  # staged through RCCL == the fused single-GPU fit, bit for bit
     np.testing.assert_array_equal(r["max_c"], r["mc_f"])
     print("compact list at an eighth of its room, one rank holding everything: status", int(r["status8"]))
@@ -231,3 +236,16 @@ def test_config4_per_rank_size_against_the_oracle(tmp_path):
     for got, sl in ((r["out_first"], slice(0, 2)), (r["out_last"], slice(62, 64))):
         want = so.macenko_transform(x[sl], r["he"], r["max_c"])
         assert np.abs(got.astype(np.float64) - want).max() <= 2.55e-2
+
+
+def test_all_512_tiles_of_config4_pooled_on_one_gpu_against_the_reference():
+    """The eight ranks' 512 tiles of BASELINE configs[3] (134 M pixels) pooled into ONE estimate by the single-GPU fit, against the REAL
+    reference's fit on the same tiles (tests/golden/g12, world8_u8)."""
+    from stainx_amd.backends.torch_hip_backend import MacenkoHIP
+
+    dev = torch.device("cuda:0")
+    g12 = load_golden("g12_config4_pooled_fit.npz")
+    world = torch.cat([synth.he_batch(64, 512, 512, seed0=1000 + 64 * r) for r in range(8)], dim=0)
+    he, max_c = MacenkoHIP(dev).compute_reference_stain_matrix(world.to(dev))
+    np.testing.assert_allclose(he.cpu().numpy(), g12["world8_u8_he"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(max_c.cpu().numpy(), g12["world8_u8_max_c"], rtol=1e-4, atol=0)
