@@ -4,9 +4,11 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload transform|fit_transform_pooled|hm_config3|module_config5|real_tiles]
 
-For N > 1 the driver launches it under ``torch.distributed.run`` (one rank per GPU, RCCL).  Tiles are
-independent units, so every rank transforms its own tiles with no data-path collective
-and the job is weak-scaled: value = N * pixels_per_rank / max-over-ranks time.
+For N > 1 the job is one rank per GPU over RCCL: either the driver launches this file under ``torch.distributed.run`` (WORLD_SIZE /
+RANK / LOCAL_RANK in the environment), or -- ``python bench.py --gpus N`` as it stands -- this process starts the N ranks ITSELF
+(a child ``torch.distributed.run`` on 127.0.0.1, before anything here touches a GPU) and passes their one JSON line through; it
+refuses loudly when the node has fewer than N GPUs.  Tiles are independent units, so every rank transforms its own tiles with no
+data-path collective and the job is weak-scaled: value = N * pixels_per_rank / max-over-ranks time.
 
 The timed loop ROTATES over two different input batches (2 x 201 MB > the 256 MiB Infinity Cache), so a call
 reads its input from HBM as a pipeline that brings fresh tiles every step does; the one-buffer figure the
@@ -99,6 +101,45 @@ def _cpu_worker(args):
     return reps * tiles.shape[0], dt
 
 
+def _cpu_worker_any(args):
+    """One worker process of the CPU baseline of the other workloads: `kind` names the oracle call, BLAS pinned to one thread."""
+    kind, sample, params, seconds = args
+    from threadpoolctl import threadpool_limits
+
+    from oracle import stain_oracle as so
+
+    fn = (lambda x: so.hm_transform(x, so.hm_fit(params[0]))) if kind == "hm" else (lambda x: so.macenko_transform(x, params[0], params[1]))
+    with threadpool_limits(limits=1):
+        fn(sample[:1])
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            fn(sample)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or reps >= 64:
+                break
+    return reps * sample.shape[0], dt
+
+
+def cpu_baseline_any(kind: str, sample, params, h: int, w: int, what: str) -> dict:
+    """The oracle on a bounded sample of a workload, one worker PROCESS per host core this job may use (16 on a one-GPU box), each on its
+    own share of the sample for ~10 s: the same protocol as the headline's cpu_baseline, so the CPU column is comparable across lines.
+    (Histogram matching pools its histogram over the batch it is given: every worker's share is its own small batch -- a throughput
+    figure, not a parity run.)"""
+    import multiprocessing as mp
+
+    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16, sample.shape[0]))
+    shares = [sample[i::cores] for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        done = pool.map(_cpu_worker_any, [(kind, sh, params, 10.0) for sh in shares])
+    wall = time.perf_counter() - t0
+    rate = sum(tiles * h * w / 1e6 / dt for tiles, dt in done)
+    return {"value": round(rate, 3), "unit": "megapixels/s", "cores": cores, "kind": "port",
+            "sample": f"{sum(t for t, _ in done)} tile transforms of {what} by {cores} worker processes side by side (numpy oracle, BLAS threads 1 each), ~10 s each, "
+                      f"{wall:.1f} s wall with start-up; host has {os.cpu_count()} cores, this job may use {cores}"}
+
+
 def cpu_baseline(n_tiles: int, x_cpu: torch.Tensor, he, max_c) -> dict:
     """Oracle (port of the reference CPU path: tiles are independent there too) on the first n_tiles tiles of the workload, one
     worker PROCESS per host core this job may use (the numpy port is single-threaded; the reference spreads its torch ops over
@@ -167,6 +208,7 @@ def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
         kernel = "histogram (LDS sub-histograms, integer counts) + LUT + apply: 3 R + 3 R + 3 W bytes per pixel moved for the 6 algorithmic"
         cpu_fn = lambda sample: so.hm_transform(sample, so.hm_fit(ref.numpy()))
         cpu_sample, exact = batches_cpu[0][:4].numpy(), True
+        cpu_kind, cpu_params, cpu_many = "hm", (ref.numpy(),), batches_cpu[0][:16].numpy()
     elif args.workload == "module_config5":
         n, h, w, bpp, dt_name = 256, 224, 224, 12, "bf16"
         ref = synth.reference_tile(h, w)
@@ -179,6 +221,7 @@ def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
         he, max_c = (t.float().cpu().numpy() for t in (module.normalizer._stain_matrix, module.normalizer._target_max_conc))
         cpu_fn = lambda sample: so.macenko_transform(sample, he, max_c)
         cpu_sample, exact = batches_cpu[0][:32].float().numpy(), False
+        cpu_kind, cpu_params, cpu_many = "macenko", (he, max_c), batches_cpu[0][:256].float().numpy()
     else:
         n, h, w, bpp, dt_name = 64, 512, 512, 24, "f32"
         imgs = torch.from_numpy(np.load(str(ROOT / "tests" / "golden" / "g11_real_images.npz"))["images_u8"])
@@ -193,6 +236,7 @@ def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
         he, max_c = norm._stain_matrix.cpu().numpy(), norm._target_max_conc.cpu().numpy()
         cpu_fn = lambda sample: so.macenko_transform(sample, he, max_c)
         cpu_sample, exact = batches_cpu[0][:16].numpy(), False
+        cpu_kind, cpu_params, cpu_many = "macenko", (he, max_c), batches_cpu[0].numpy()
     batches = [b.to(dev) for b in batches_cpu]
     pixels = n * h * w
     for i in range(args.warmup):
@@ -214,20 +258,9 @@ def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
         engine = norm._get_backend_impl()
         line["form"] = "four-pass (the two-pass form left its speculative path on some tiles; the backend's feedback switched)" if int(engine._classic_left) > 0 else "two-pass"
     if world == 1 and not args.no_cpu:
-        from threadpoolctl import threadpool_limits
-
-        with threadpool_limits(limits=1):
-            want = cpu_fn(cpu_sample)
-            reps, t0 = 1, time.perf_counter()
-            while True:
-                cpu_fn(cpu_sample)
-                reps += 1
-                dt = time.perf_counter() - t0
-                if dt >= 10.0 or reps >= 32:
-                    break
+        want = cpu_fn(cpu_sample)
         k = cpu_sample.shape[0]
-        line["cpu_baseline"] = {"value": round((reps - 1) * k * h * w / 1e6 / dt, 3), "unit": "megapixels/s", "cores": 1, "kind": "port",
-                                "sample": f"{reps - 1} x the first {k} tiles of the workload, numpy oracle on one core, {dt:.1f} s; host has {os.cpu_count()} cores"}
+        line["cpu_baseline"] = cpu_baseline_any(cpu_kind, cpu_many, cpu_params, h, w, f"the workload's first {cpu_many.shape[0]} tiles ({h}x{w} {dt_name})")
         # parity of a GPU result against the oracle on the same sample (HM pools its histogram over the batch it is given: the sample alone)
         got = call(batches[0][:k].contiguous()).float().cpu()
         w_t = torch.from_numpy(np.asarray(want)).float() / (255.0 if args.workload == "module_config5" else 1.0)
@@ -239,8 +272,67 @@ def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
     os.dup2(2, 1)
 
 
+def launcher_command(n_gpus: int, argv: list[str], port: int) -> list[str]:
+    """The command that starts one rank per GPU of this node for `python bench.py --gpus N ...` (what the driver's own wrapper does)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            str(Path(__file__).resolve()), *argv]
+
+
+def launch_ranks(args) -> int:
+    """`--gpus N` with N > 1 and no rank environment: start the N ranks as children (this process has not touched a GPU:
+    torch.cuda.device_count() does not initialise one) and return their exit code; their rank 0 prints the line."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("STAINX_BENCH_REHEARSE"):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} GPU(s); refusing to time fewer GPUs than asked for "
+                         "(STAINX_BENCH_REHEARSE=1 puts all ranks on the GPUs there are: a rehearsal of the N > 1 path, not a measurement)")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    return subprocess.run(launcher_command(args.gpus, sys.argv[1:], port), check=False).returncode
+
+
+def real_tiles_record(dev, steps: int, barrier) -> dict:
+    """The headline transform on 64 crops of 512 x 512 from the reference's own example images (tests/golden/g11_real_images.npz) instead of
+    synthetic tiles, rotating two batches: what `--workload real_tiles` prints as its own line, in short, for the default line."""
+    import numpy as np
+
+    from stainx_amd import Macenko, synth
+
+    path = ROOT / "tests" / "golden" / "g11_real_images.npz"
+    if not path.exists():
+        return {"skipped": "tests/golden/g11_real_images.npz is not in this tree"}
+    imgs = torch.from_numpy(np.load(str(path))["images_u8"])
+    crops = torch.stack([imgs[i, :, y:y + 512, x:x + 512] for i in range(6) for y in range(0, 513, 128) for x in range(0, 513, 128)])
+    batches = [synth.as_dtype(crops[torch.arange(b, 150, 150 / 64).long()[:64]], torch.float32).to(dev) for b in range(2)]
+    norm = Macenko(device=dev, backend="torch_hip").fit(imgs[0:1].to(dev))
+    first = []
+    for i in range(8):      # the first calls on this data, one by one: is there a cliff before any feedback?
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        norm.transform(batches[i % 2])
+        e1.record()
+        torch.cuda.synchronize(dev)
+        first.append(e0.elapsed_time(e1))
+    for i in range(30):
+        norm.transform(batches[i % 2])
+    elapsed, step_ms, _ = timed_loop(lambda i: norm.transform(batches[i % 2]), steps, barrier)
+    dev_ms = sum(step_ms) / len(step_ms)
+    engine = norm._get_backend_impl()
+    fell = engine.tile_params(64)["fell_back"]
+    pixels = 64 * 512 * 512
+    return {"ms_per_step": round(elapsed / steps * 1e3, 4), "device_ms_per_call": round(dev_ms, 4), "device_ms_max": round(max(step_ms), 4), "device_ms_median": round(sorted(step_ms)[len(step_ms) // 2], 4),
+            "frac": round(pixels * BYTES_PER_PIXEL / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "first_calls_ms": [round(v, 4) for v in first],
+            "slow_slots_last_call": int(sum(bin(int(v) & 15).count("1") for v in fell)), "steps": steps,
+            "data": "64 crops (512 x 512) of the reference's six example images, float32, two batches rotated"}
+
+
 def main() -> None:
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     # Only the result line may reach stdout: libraries underneath print there (RCCL's version banner at communicator
     # creation, for one), so file descriptor 1 points at stderr until the line is written.
     sys.stdout.flush()
@@ -394,6 +486,8 @@ def main() -> None:
                                              "note": f"the only launch that moves the full 24 B/px; its rocprofv3 average is in {KERNEL_STATS}"}},
             "kernel_source_hash": source_hash(),
         }
+        if not os.environ.get("STAINX_BENCH_NO_REAL"):
+            line["real_tiles"] = real_tiles_record(dev, min(args.steps, 200), lambda: torch.cuda.synchronize(dev))
         if os.environ.get("STAINX_BENCH_REHEARSE"):
             line["rehearsal"] = "ranks share ONE GPU (gloo for the barrier and the max): a run of the N > 1 code path, not a measurement"
         if world == 1 and not args.no_cpu:

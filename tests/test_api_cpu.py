@@ -5,6 +5,7 @@ and that the product never falls back to the CPU."""
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 from pathlib import Path
 
@@ -216,3 +217,22 @@ def test_force_collectives_flag_is_parsed_and_read_late(monkeypatch):
     monkeypatch.setattr(sxd, "FORCE_COLLECTIVES", True)
     monkeypatch.setenv("STAINX_FORCE_COLLECTIVES", "0")
     assert sxd.force_collectives() is True
+
+
+def test_bench_gpus_n_starts_n_ranks_or_refuses():
+    """`python bench.py --gpus N` without a rank environment starts the N ranks itself (one per GPU, torch.distributed.run on 127.0.0.1)
+    and refuses loudly on a node with fewer GPUs (the flag used to be parsed and never read)."""
+    import subprocess
+    import sys
+
+    import bench
+
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "7"], 29777)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777"
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    # no GPU in this container: the launcher path is taken and refuses (a non-zero exit, the reason on stderr) before any rank starts
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "STAINX_BENCH_REHEARSE")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "refusing to time fewer GPUs" in r.stderr, (r.returncode, r.stderr[-500:])
