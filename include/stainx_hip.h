@@ -40,29 +40,32 @@ typedef enum {
     SX_ERR_LAUNCH = 4      /* hipGetLastError() after a launch (reference: macenko.cu:125-126) */
 } sx_status;
 
-/* flags for sx_macenko_transform */
+/* flags for sx_macenko_transform: the six public bits */
 #define SX_MACENKO_NORMALIZE_0_1 1u /* fuse `result / 255.0` (normalizers/_template.py:111-112); u8 input -> f32 output */
+#define SX_MACENKO_CHANNELS_LAST 2u /* images and output are (N,H,W,3) (decoder / PIL layout) instead of (N,3,H,W); an extension: the
+                                      reference takes NCHW only and callers permute + copy first (SURVEY.md 8f-2) */
 #define SX_MACENKO_SAMPLED 4u       /* an APPROXIMATION (not a parity path, not the reference's precision="fast"): the percentiles of a 4096-pixel
                                       sample of each tile stand in for the exact ones -- moments pass, one per-tile stage, reconstruct.  Mean
                                       error ~0.5, worst ~5 grey levels on H&E tiles.  Macenko(precision="sampled") in the Python host; the
                                       reference's precision="fast" (fp16 tensors, exact percentiles, MAE ~0.05) is served by the exact path. */
+#define SX_MACENKO_CLASSIC 16u       /* the four-pass form of the transform even where the two-pass form would be chosen (same bits; callers whose
+                                       batches hold tiles the two-pass form cannot speculate on: see sx_macenko_telemetry_offset) */
 #define SX_MACENKO_OUT_BF16 32u      /* uint8 input only: the result is written as bfloat16 -- bit for bit `transform(x).to(bfloat16)`, with
                                        SX_MACENKO_NORMALIZE_0_1 `transform(x, normalize_to_0_1).to(bfloat16)` -- so a uint8 tile from the decoder
                                        becomes a model's bf16 input with 3 bytes read and 6 written per pixel (an extension: SURVEY.md 8f-2) */
 #define SX_MACENKO_OUT_F16 64u       /* the same with float16 */
-#define SX_MACENKO_CLASSIC 16u       /* the four-pass form of the transform even where the two-pass form would be chosen (same bits; A/B runs, tests,
-                                       callers whose batches hold tiles without tissue: see sx_macenko_telemetry_offset) */
-#define SX_MACENKO_TWO_PASS 256u     /* the two-pass form wherever it can run (by default only where it is the faster one: f32 / f64 batches of
-                                       >= 4 M pixels, tiles of 128x128 ... 724x724) */
-#define SX_MACENKO_FUSE 512u         /* the two-pass form with its last three launches (pass A, stage, reconstruct) as ONE launch with tile-level
-                                       dependencies, where it can run that way (planar float32 tiles of 128x128 ... 512x512; same bits).  Opt-in:
-                                       measured slower than the four launches on MI355X; kept for A/B runs and tests */
-#define SX_MACENKO_SPEC_FAIL 128u    /* diagnostic: the two-pass form treats every speculation as failed (forces its slow exact path; tests) */
-#define SX_MACENKO_NO_TIE_SHORTCUT 8u /* diagnostic: do not resolve a bracket that closed on one key from its counts (forces the slow exact paths; tests) */
-#define SX_MACENKO_RESIDENT 1024u    /* the tile-resident form (one launch; pixels kept on chip as 8-bit codes) wherever it can run -- by default only where it
-                                        has been measured to be the faster one; tests, A/B runs */
-#define SX_MACENKO_CHANNELS_LAST 2u /* images and output are (N,H,W,3) (decoder / PIL layout) instead of (N,3,H,W); an extension: the
-                                      reference takes NCHW only and callers permute + copy first (SURVEY.md 8f-2) */
+
+/* Diagnostic builds only (-DSX_DIAG: stainx_amd/_lib/libstainx_diag.so, built next to the product by __graft_entry__.build(); the product
+   library refuses these bits with SX_ERR_BAD_ARG).  Tests force the rare paths with them; two measured-and-slower forms of the transform
+   live there as design studies (DESIGN.md sections 4c, 4e). */
+#ifdef SX_DIAG
+#define SX_MACENKO_NO_TIE_SHORTCUT 8u /* do not resolve a bracket that closed on one key from its counts (forces the slow exact paths) */
+#define SX_MACENKO_SPEC_FAIL 128u    /* the two-pass form treats every speculation as failed (forces its slow exact path) */
+#define SX_MACENKO_TWO_PASS 256u     /* the two-pass form wherever it can run (by default only where it is the faster one) */
+#define SX_MACENKO_FUSE 512u         /* the two-pass form with its last three launches as ONE launch with tile-level dependencies (planar float32 tiles of
+                                       128x128 ... 512x512; same bits; slower: DESIGN.md 4c) */
+#define SX_MACENKO_RESIDENT 1024u    /* the tile-resident form: one launch, a tile's pixels kept on chip as 8-bit codes (same bits; slower: DESIGN.md 4e) */
+#endif
 
 int sx_version(void);
 const char* sx_last_error_string(void);
@@ -213,7 +216,10 @@ int sx_reinhard_transform(const void* images_dev, void* out_dev, int dtype, int6
  * counters in front of the statistics pass (~4 us of a 130 us call on 64 x 3 x 512 x 512 float32).  The plain calls above accept ANY
  * workspace contents and leave it ready as well.  A ready call on a workspace that was not ready is noticed on the device (the apply
  * pass does not find the statistics of its own statistics pass): bit 0 of the uint32 at byte sx_reinhard_workspace_status_offset()
- * is set; the output of such a call is not to be used.  No reference counterpart (the reference keeps no state between calls). */
+ * is set; the output of such a call is not to be used.  The state a ready call relies on (the arrival counters) lies at a place that does
+ * NOT depend on the batch's shape (batches of up to 4096 tiles; a larger batch is served as by the plain call), so calls of different
+ * shapes may alternate on one ready workspace -- also when replayed from a captured graph.  No reference counterpart (the reference
+ * keeps no state between calls). */
 int sx_reinhard_workspace_init(void* workspace_dev, size_t workspace_bytes, void* stream);
 size_t sx_reinhard_workspace_status_offset(void);
 int sx_reinhard_transform_ready(const void* images_dev, void* out_dev, int dtype, int64_t n_tiles, int64_t height,

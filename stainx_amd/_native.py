@@ -15,19 +15,22 @@ import torch
 
 ABI_VERSION = 1
 LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libstainx_hip.so"
+DIAG_LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libstainx_diag.so"      # -DSX_DIAG build: diagnostic flags, design-study forms, stage stamps (tests / tools)
 
 SX_OK, SX_ERR_BAD_ARG, SX_ERR_DTYPE, SX_ERR_WORKSPACE, SX_ERR_LAUNCH = range(5)
 MACENKO_NORMALIZE_0_1 = 1
 MACENKO_CHANNELS_LAST = 2
 MACENKO_SAMPLED = 4
-MACENKO_NO_TIE_SHORTCUT = 8
 MACENKO_CLASSIC = 16
 MACENKO_OUT_BF16 = 32
 MACENKO_OUT_F16 = 64
+# diagnostic build only (libstainx_diag.so; the product library refuses these bits)
+MACENKO_NO_TIE_SHORTCUT = 8
 MACENKO_SPEC_FAIL = 128
 MACENKO_TWO_PASS = 256
 MACENKO_FUSE = 512
 MACENKO_RESIDENT = 1024
+MACENKO_DIAG_BITS = MACENKO_NO_TIE_SHORTCUT | MACENKO_SPEC_FAIL | MACENKO_TWO_PASS | MACENKO_FUSE | MACENKO_RESIDENT
 MACENKO_PARAM_FLOATS = 48
 PFIT_STATS_RECORD_BYTES = 49240
 PFIT_SUMS = 1033
@@ -88,25 +91,43 @@ SIGNATURES = {
 
 _lib = None
 _load_error: str | None = None
+_diag_lib = None
+
+
+def _open(path: Path):
+    lib = ctypes.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    got = lib.sx_version()
+    if got != ABI_VERSION:
+        raise OSError(f"ABI version {got} != expected {ABI_VERSION}")
+    return lib
 
 
 def _load():
     global _lib, _load_error
     if _lib is not None or _load_error is not None:
         return _lib
-    path = Path(os.environ.get("STAINX_HIP_LIB", LIB_PATH))
+    # STAINX_DIAG=1: the diagnostic build stands in for the product (tools that A/B the forms); STAINX_HIP_LIB names any other build
+    default = DIAG_LIB_PATH if os.environ.get("STAINX_DIAG", "").strip().lower() in ("1", "true", "yes", "on") else LIB_PATH
+    path = Path(os.environ.get("STAINX_HIP_LIB", default))
     try:
-        lib = ctypes.CDLL(str(path))
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
-        got = lib.sx_version()
-        if got != ABI_VERSION:
-            raise OSError(f"ABI version {got} != expected {ABI_VERSION}")
-        _lib = lib
+        _lib = _open(path)
     except (OSError, AttributeError) as exc:
         _load_error = f"{path}: {exc}"
     return _lib
+
+
+def require_diag():
+    """The diagnostic build (libstainx_diag.so): the product's code plus the diagnostic flags and the design-study forms.  Tests and tools."""
+    global _diag_lib
+    if _diag_lib is None:
+        try:
+            _diag_lib = _open(DIAG_LIB_PATH)
+        except (OSError, AttributeError) as exc:
+            raise ImportError(f"libstainx_diag.so is not built or not loadable ({DIAG_LIB_PATH}: {exc}); `python -c 'import __graft_entry__ as g; g.build()'` builds it next to the product") from None
+    return _diag_lib
 
 
 def library_available() -> bool:
@@ -137,14 +158,14 @@ def require():
     return lib
 
 
-def last_error() -> str:
-    return require().sx_last_error_string().decode("utf-8", "replace")
+def last_error(lib=None) -> str:
+    return (lib or require()).sx_last_error_string().decode("utf-8", "replace")
 
 
-def check(code: int, what: str) -> None:
+def check(code: int, what: str, lib=None) -> None:
     if code == SX_OK:
         return
-    msg = f"{what} failed (status {code}): {last_error()}"
+    msg = f"{what} failed (status {code}): {last_error(lib)}"
     raise RuntimeError(msg)      # the reference's TORCH_CHECK failures surface as RuntimeError too
 
 

@@ -54,8 +54,10 @@ class TorchHIPBackendBase:
 class MacenkoHIP(TorchHIPBackendBase):
     """Macenko transform / fit on the GPU (numerics of MacenkoTorch, torch_backend.py:358-560)."""
 
-    def __init__(self, device: str | torch.device | None = None, precision: str = "stable"):
+    def __init__(self, device: str | torch.device | None = None, precision: str = "stable", diag: bool = False):
         super().__init__(device)
+        if diag:      # tests / tools: the diagnostic build (its flags force the rare paths; the design-study forms live there)
+            self._lib = _native.require_diag()
         if precision not in ("stable", "fast", "sampled"):
             raise ValueError(f"precision must be 'stable' or 'fast' (or the extension 'sampled'), got {precision!r}")
         # "stable" and "fast" run the SAME exact kernels (fp64 covariance, exact nearest-rank percentiles).  The reference's "fast"
@@ -138,7 +140,7 @@ class MacenkoHIP(TorchHIPBackendBase):
                     flags |= self._route()
             rc = self._lib.sx_macenko_transform(images.data_ptr(), out.data_ptr(), code, n, h, w, sm.data_ptr(), tmc.data_ptr(),
                                                 flags, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
-            _native.check(rc, "sx_macenko_transform")
+            _native.check(rc, "sx_macenko_transform", self._lib)
             if routed and not (flags & _native.MACENKO_CLASSIC):
                 with self._tele_lock:
                     self._watch(ws)

@@ -2595,8 +2595,13 @@ __global__ void export_params_kernel(const GroupState* __restrict__ state, int64
 }  // namespace macenko
 }  // namespace sx
 #include "macenko_twopass.hpp"
+// Diagnostic builds only (-DSX_DIAG: stainx_amd/_lib/libstainx_diag.so, built next to the product by __graft_entry__.build()): two forms of the
+// transform that were built, are exact and are SLOWER than the product's forms on every measured input -- kept as measured design studies
+// (DESIGN.md sections 4c, 4e), not shipped -- and the flags that force the rare paths for tests.
+#ifdef SX_DIAG
 #include "macenko_fused.hpp"
 #include "macenko_resident.hpp"
+#endif
 namespace sx {
 namespace macenko {
 static_assert(sizeof(PriorRecord) == kPriorRecordBytes, "workspace layout");
@@ -2703,6 +2708,7 @@ static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws,
     return check_launch("macenko two-pass estimate");
 }
 
+#ifdef SX_DIAG
 // The fused two-pass transform (macenko_fused.hpp): the prior, then pass A + stage jobs + reconstruct items in ONE launch.
 template <typename T, typename O, int V>
 static int run_fused(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
@@ -2715,6 +2721,8 @@ static int run_fused(const T* images, O* out, const Geometry& g, const Workspace
     return check_launch("macenko fused transform");
 }
 
+#endif
+
 template <typename T, typename O, int V, bool kInter = false>
 static int run_transform(const T* images, O* out, const Geometry& g, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
     const unsigned items = (unsigned)(g.n_tiles * (g.recon_chunk ? g.recon_blocks : (g.fine_chunk ? g.fine_blocks : g.blocks_per_tile)));      // reconstruct work items
@@ -2726,7 +2734,9 @@ static int run_transform(const T* images, O* out, const Geometry& g, const Works
     } else if (g.two_pass) {
         // (the output tile doubles as scratch for the keys of a slot that takes the slow exact path: nothing has been written there
         // yet, the reconstruct launch overwrites it -- needs a plane of 4-byte elements per slot pair)
-        rc = run_two_pass<T, V, kInter>(images, g, ws, tmc, stream, sizeof(O) >= 4 ? static_cast<void*>(out) : nullptr);
+        // (float64 tiles take the four passes: sx_macenko_form never sends them here, and their two-pass kernels -- 0.4 MB of code -- are not built)
+        if constexpr (sizeof(T) == 8) rc = fail(SX_ERR_DTYPE, "the two-pass form is not built for float64 tiles");
+        else rc = run_two_pass<T, V, kInter>(images, g, ws, tmc, stream, sizeof(O) >= 4 ? static_cast<void*>(out) : nullptr);
     } else {
         rc = run_estimate<T, V, kInter>(images, g, ws, (int)g.n_tiles, 1, tmc, nullptr, nullptr, stream);
     }
@@ -2753,6 +2763,7 @@ static int run_transform(const T* images, O* out, const Geometry& g, const Works
     return check_launch("macenko reconstruct");
 }
 
+#ifdef SX_DIAG
 // ---- the tile-resident form (macenko_resident.hpp) ---------------------------------------------------------------------------
 // Compute units of the current device (the launch must be resident at once: one 1024-thread workgroup per CU); 256 when no device
 // can be asked (workspace sizing on a host without one).
@@ -2823,6 +2834,8 @@ static int resident_transform(const void* images, void* out, int dtype, int64_t 
         default: return fail(SX_ERR_DTYPE, "the resident form takes uint8 / float16 / bfloat16 / float32 tiles");
     }
 }
+
+#endif
 
 template <typename T>
 static int transform_typed(const void* images, void* out, const Geometry& g0, const Workspace& ws, const float* sm, const float* tmc, bool unit, hipStream_t stream) {
@@ -2924,9 +2937,11 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
                        : run_transform<T, float, 1>(in, static_cast<float*>(out), g, ws, sm, tmc, true, stream);
         }
     }
+#ifdef SX_DIAG
     if constexpr (std::is_same<T, float>::value) {
         if (g.fused) return run_fused<T, T, W>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream);
     }
+#endif
     return vec ? run_transform<T, T, W>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream)
                : run_transform<T, T, 1>(in, static_cast<T*>(out), g, ws, sm, tmc, unit, stream);
 }
@@ -3197,7 +3212,11 @@ static int validate_images(const void* images, int64_t n, int64_t h, int64_t w, 
 
 extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, int64_t width) {
     if (n_tiles <= 0 || height <= 0 || width <= 0) return 0;
+#ifdef SX_DIAG
     return std::max(macenko::workspace_bytes(n_tiles, height * width), macenko::resident_bytes(n_tiles, height * width));
+#else
+    return macenko::workspace_bytes(n_tiles, height * width);
+#endif
 }
 
 // Which form sx_macenko_transform takes for a call: 0 the four passes, 1 the two-pass form as four launches, 2 the two-pass form
@@ -3210,18 +3229,22 @@ extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, in
 extern "C" int sx_macenko_form(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) {
     if (n <= 0 || h <= 0 || w <= 0 || (flags & SX_MACENKO_SAMPLED)) return 0;
     const int64_t pixels = h * w;
-    // 3: the tile-resident form (macenko_resident.hpp) -- asked for (SX_MACENKO_RESIDENT), or by default where it pays
-    if (!(flags & (SX_MACENKO_CLASSIC | SX_MACENKO_TWO_PASS | SX_MACENKO_FUSE)) && resident_able(dtype, n, pixels, flags)) {
-        if ((flags & SX_MACENKO_RESIDENT) != 0) return 3;      // (opt-in: measured slower than the multi-launch forms so far -- DESIGN.md section 4e)
-    }
+#ifdef SX_DIAG
+    // 3: the tile-resident form (macenko_resident.hpp), diagnostic builds, where asked for (measured slower than the multi-launch forms: DESIGN.md 4e)
+    if ((flags & SX_MACENKO_RESIDENT) != 0 && !(flags & (SX_MACENKO_CLASSIC | SX_MACENKO_TWO_PASS | SX_MACENKO_FUSE)) && resident_able(dtype, n, pixels, flags)) return 3;
+    const unsigned forced_two_pass = flags & SX_MACENKO_TWO_PASS, fuse = flags & SX_MACENKO_FUSE;
+#else
+    const unsigned forced_two_pass = 0u, fuse = 0u;
+#endif
     // (narrow pixels -- uint8 / f16 / bf16 -- since the candidates travel as dense records: tiles of ~360 x 360 ... 512 x 512, where the
     // two-pass form saves two instruction-bound passes -- uint8 64 x 512 x 512: 106 us against 118, bf16 126 against 144; at 320 x 320 and
     // below, and on the per-wave segments of larger tiles, the four passes win: tools/bench_twopass.py, profiles/r03_forms_by_dtype_and_tile.jsonl)
-    const bool wide = dtype == SX_F32 || dtype == SX_F64;
+    if (dtype == SX_F64) return 0;      // (a rare element type: the four passes serve it)
+    const bool wide = dtype == SX_F32;
     const bool pays = n * pixels >= (1ll << 22) && (wide ? (pixels >= 36864 && pixels <= (1ll << 19)) : (pixels >= 131072 && pixels <= 262144));
-    const bool wanted = (flags & SX_MACENKO_TWO_PASS) != 0 || (pays && !(flags & SX_MACENKO_CLASSIC));
+    const bool wanted = forced_two_pass != 0 || (pays && !(flags & SX_MACENKO_CLASSIC));
     if (!(wanted && two_pass_size(pixels))) return 0;
-    const bool fusable = (flags & SX_MACENKO_FUSE) != 0 && dtype == SX_F32 && fused_size(pixels) && !(flags & SX_MACENKO_CHANNELS_LAST);
+    const bool fusable = fuse != 0 && dtype == SX_F32 && fused_size(pixels) && !(flags & SX_MACENKO_CHANNELS_LAST);
     return fusable ? 2 : 1;
 }
 extern "C" int sx_macenko_takes_two_pass(int dtype, int64_t n, int64_t h, int64_t w, unsigned flags) { const int f = sx_macenko_form(dtype, n, h, w, flags); return (f == 1 || f == 2) ? 1 : 0; }
@@ -3233,7 +3256,9 @@ extern "C" size_t sx_macenko_workspace_bytes_for(int dtype, int64_t n_tiles, int
     if (n_tiles <= 0 || height <= 0 || width <= 0) return 0;
     const int form = sx_macenko_form(dtype, n_tiles, height, width, flags);
     // (the resident form's buffer also serves the four passes: a call whose pointers turn out not to be 16-byte aligned takes those)
+#ifdef SX_DIAG
     if (form == 3) return std::max(macenko::resident_bytes(n_tiles, height * width), macenko::workspace_bytes(n_tiles, height * width, kWsBase));
+#endif
     // (the four-launch two-pass form keeps its candidates in the dense record arrays too for tiles up to 512 x 512: only larger
     // tiles need the per-wave segments)
     const bool dense = form != 0 && fused_size(height * width);
@@ -3249,16 +3274,23 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
     Geometry g = make_geometry(n, h * w, 0);
     g.interleaved = (flags & SX_MACENKO_CHANNELS_LAST) ? 1 : 0;
     g.fast = (flags & SX_MACENKO_SAMPLED) ? 1 : 0;
+#ifdef SX_DIAG
     g.no_tie = (flags & SX_MACENKO_NO_TIE_SHORTCUT) ? 1 : 0;
-    g.out_code = (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0);
     g.spec_fail = (flags & SX_MACENKO_SPEC_FAIL) ? 1 : 0;
+#else
+    if (flags & ~(SX_MACENKO_NORMALIZE_0_1 | SX_MACENKO_CHANNELS_LAST | SX_MACENKO_SAMPLED | SX_MACENKO_CLASSIC | SX_MACENKO_OUT_BF16 | SX_MACENKO_OUT_F16))
+        return fail(SX_ERR_BAD_ARG, "flags 0x%x: bits outside the public set (the diagnostic flags need the diagnostic build, -DSX_DIAG)", flags);
+#endif
+    g.out_code = (flags & SX_MACENKO_OUT_BF16) ? SX_BF16 : ((flags & SX_MACENKO_OUT_F16) ? SX_F16 : 0);
     int form = sx_macenko_form(dtype, n, h, w, flags);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     const bool unit = (flags & SX_MACENKO_NORMALIZE_0_1) != 0;
+#ifdef SX_DIAG
     if (form == 3) {
         if (aligned_for(images, 16) && aligned_for(out, 16)) return resident_transform(images, out, dtype, n, h * w, ws_ptr, sm, tmc, unit, stream);
         form = 0;
     }
+#endif
     g.two_pass = form != 0 ? 1 : 0;
     g.fused = form == 2 ? 1 : 0;
     const Workspace ws = carve(ws_ptr, n, g.pixels);

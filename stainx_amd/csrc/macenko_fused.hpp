@@ -13,9 +13,13 @@
 //   tickets [A + 2 N, ...)  reconstruct work items, tile-major: wait for the tile's two stage jobs (s_done == 2), then the
 //                           unchanged reconstruct_item
 //
-// A unit only ever waits for units with LOWER tickets, i.e. for workgroups that are already running or done: no assumption
-// about co-residency or dispatch order, every wait is bounded all the same (a timeout is counted in GroupState::spin_timeouts
-// and the workgroup leaves).  The hardware's own dispatcher does the scheduling: the 4 x 256 CUs' worth of resident workgroups
+// A unit waits for units with LOWER tickets -- workgroups that are already running or done -- with ONE exception: stage job (tile, 0)
+// also waits for the angle key of its partner (tile, 1), which holds the NEXT ticket of the same queue and may not have been handed
+// out yet.  That is safe because (a) the two tickets are adjacent, so at most one such pair per queue is ever split across a
+// dispatch boundary, (b) the wait is bounded (~2^21 polls) and (c) a partner that does not show up is replaced by the exact slow
+// select of its percentile in the waiting job itself: no deadlock, no assumption about co-residency or dispatch order, only time
+// lost (a timeout is counted in GroupState::spin_timeouts and the workgroup goes on; ADVICE r3 corrected this paragraph, which used
+// to claim the lower-ticket rule without the exception).  The hardware's own dispatcher does the scheduling: the 4 x 256 CUs' worth of resident workgroups
 // start as pass A; as they retire (the oldest quarter of the tiles first: s_setprio by ticket quarter on top of the CU's
 // oldest-first arbitration) the freed slots take stage jobs and then reconstruct items, which sit waiting on the CU for their
 // tile's stage and start the moment it publishes.  So a tile's stage runs while later tiles still stream through pass A, and

@@ -9,6 +9,7 @@
 // LAB is recomputed in pass 2 instead of being stored: 24 VALU-cheap transcendentals per pixel are
 // cheaper than a 12 B/px round trip through HBM.
 #include "common.hpp"
+#include <algorithm>
 #include <atomic>
 #include <cstddef>
 
@@ -367,7 +368,14 @@ static int blocks_for(int64_t n, int64_t pixels) {
     return (int)((pixels + chunk - 1) / chunk);
 }
 static size_t partial_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(double) * kSums * (size_t)blocks_for(n, pixels) * (size_t)n, 256); }
-static size_t workspace_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(State), 256) + partial_bytes(n, pixels) + align_up(sizeof(unsigned int) * kTileCounterStride * (size_t)n, 256); }
+// The per-tile arrival counters lie directly behind the State, in front of the partial sums, in a region of FIXED size for batches of up to
+// kReadyTiles tiles: a completed call of ANY shape then leaves every counter of every shape zero (with the counters behind the partial
+// sums -- whose size follows the shape -- a call of one shape left its fp64 sums where another shape's counters lie: a READY call of that
+// other shape never saw its last arrival and normalised with stale statistics).  Larger batches: the region grows with the
+// batch and a READY call is treated as a plain one (the clearing launch runs).
+constexpr int64_t kReadyTiles = 4096;
+static size_t counter_bytes(int64_t n) { return align_up(sizeof(unsigned int) * kTileCounterStride * (size_t)std::max<int64_t>(n, kReadyTiles), 256); }
+static size_t workspace_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(State), 256) + counter_bytes(n) + partial_bytes(n, pixels); }
 
 __global__ void init_state_kernel(State* st, unsigned int* tile_arrivals, int64_t n_tiles) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -394,8 +402,9 @@ template <typename T>
 static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, float* mean_out, float* std_out, double* sums_out, const double* sums_in, double n_total, void* ws, hipStream_t stream, bool ready) {
     Geometry g{n, h * w, blocks_for(n, h * w), kStreamThreads * 4 * sweeps_for(n, h * w)};
     State* st = static_cast<State*>(ws);
-    double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + align_up(sizeof(State), 256));
-    unsigned int* tile_arrivals = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(partial) + partial_bytes(n, h * w));
+    unsigned int* tile_arrivals = reinterpret_cast<unsigned int*>(static_cast<char*>(ws) + align_up(sizeof(State), 256));
+    double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(tile_arrivals) + counter_bytes(n));
+    if (n > kReadyTiles) ready = false;      // (the counters of such a batch do not lie in the shape-independent region)
     const bool vec = (g.pixels % 4 == 0) && (reinterpret_cast<uintptr_t>(images) % (sizeof(T) * 4) == 0) && (!out || reinterpret_cast<uintptr_t>(out) % (sizeof(T) * 4) == 0);
     const unsigned grid = (unsigned)(n * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);

@@ -189,10 +189,11 @@ def _macenko_fit_pooled(local_images, group, steps, method: str, defer_status: b
         result = _macenko_fit_pooled_brackets(local_images, group, steps)      # (raises on EVERY rank if some rank holds no tile)
         he, max_c, status = result
         if defer_status and status.is_cuda:
-            host = torch.empty(1, dtype=torch.int32).pin_memory()
-            host.copy_(status, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
+            host = torch.ones(1, dtype=torch.int32).pin_memory()      # (non-zero until the copy lands: a premature look repeats the fit, never accepts it)
+            with torch.cuda.device(status.device):
+                host.copy_(status, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(status.device))      # (the stream the copy was queued on, whatever the current device is)
 
             def held() -> bool:
                 done.synchronize()      # (a four-byte copy queued BEFORE the transform: long done by the time the host gets here)
@@ -207,7 +208,9 @@ def _macenko_fit_pooled(local_images, group, steps, method: str, defer_status: b
         if code & 16 and not _retried:      # the cached tile counts were stale: once more with fresh ones (still the bracket form)
             _TILE_COUNTS.clear()
             return _macenko_fit_pooled(local_images, group, steps, method, defer_status, _retried=True)
-        # (anything else -- a bracket that missed, or a stale flag that survives fresh counts -- goes on to the radix rounds below)
+        # (anything else -- a bracket that missed, a stale flag that survives fresh counts, a rank without tiles -- goes on to the radix rounds
+        # below, behind the tile-count check EVERY rank takes part in: a rank without tiles fails there on every rank)
+        tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
     else:
         # (both methods: a rank without tiles must fail on EVERY rank here, not leave the others in the next collective)
         tiles_per_rank(int(local_images.shape[0]), _exchange_device(steps, local_images), group)
@@ -277,8 +280,8 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _shar
             tiles, stale = [int(v) for v in counts_dev.tolist()], None      # (the one early host read: only the first pass is queued)
             if min(tiles) > 0:
                 _TILE_COUNTS[key] = (tiles, counts_dev.clone())
-        if min(tiles) <= 0:
-            raise ValueError(f"every rank needs at least one tile for a pooled statistic, got tiles per rank {tiles} (shard with shard_bounds over >= world_size tiles)")
+        if min(tiles) <= 0:      # (known only to the ranks that read the counts afresh: see _sit_out)
+            return _sit_out(group, counts_dev.device, len(tiles), int(_share) if _share else 32768 // len(tiles))
         size = len(tiles)
         moments = got[:, 8:88].contiguous().view(torch.float64).sum(dim=0)                   # the same sum on every rank
         samples = got[:, 88:].contiguous().view(torch.float32).reshape(size, 3, 4096)
@@ -322,6 +325,23 @@ def _macenko_fit_pooled_brackets(local_images: torch.Tensor, group, steps, _shar
     return out
 
 
+_ZERO_TILES = 16 | 32      # status of an attempt some rank had no tile for: "stale" (everybody repeats once with fresh counts) and "no tiles"
+
+
+def _sit_out(group, device, size: int, share: int):
+    """Some rank holds no tile.  A rank that has just READ the tile counts knows; a rank that took its cached counts on trust does not
+    (its device-side check will say "stale" at the end of the attempt) and goes on into the attempt's remaining exchanges -- so the
+    ranks that know take part in those with empty records instead of raising alone and leaving the others in a collective until it
+    times out.  Everybody then meets again: the attempt's status is "stale | no tiles" on the ranks that sat out and
+    "stale" on the others, all repeat once with fresh counts, all see the empty shard, all sit out, and all raise behind the radix
+    path's tile-count exchange."""
+    for _stage in (0, 1):
+        all_reduce_sum(torch.zeros(1033, dtype=torch.int64, device=device), group)
+        all_gather_stack(torch.zeros(3 + 2 * int(share), dtype=torch.int32, device=device), group)
+    zeros = torch.zeros
+    return zeros((3, 2), dtype=torch.float32, device=device), zeros(2, dtype=torch.float32, device=device), torch.full((1,), _ZERO_TILES, dtype=torch.int32, device=device)
+
+
 def _macenko_fit_pooled_brackets_packed(local_images: torch.Tensor, group, steps, shape: tuple[int, int, int], _share: int | None):
     """The five exchanges with the records packed and unpacked by the steps provider (include/stainx_hip.h, sx_macenko_pfit_*_packed):
     the host moves buffers it never looks into -- except the ranks' tile counts, once per (group, local shape)."""
@@ -341,8 +361,8 @@ def _macenko_fit_pooled_brackets_packed(local_images: torch.Tensor, group, steps
         tiles, expected = [int(v) for v in counts_dev.tolist()], None      # (the one early host read: only the first pass is queued)
         if min(tiles) > 0:
             _TILE_COUNTS[key] = (tiles, counts_dev.clone())
-    if min(tiles) <= 0:
-        raise ValueError(f"every rank needs at least one tile for a pooled statistic, got tiles per rank {tiles} (shard with shard_bounds over >= world_size tiles)")
+    if min(tiles) <= 0:      # (known only to the ranks that read the counts afresh: see _sit_out)
+        return _sit_out(group, got.device, size, int(_share) if _share else 32768 // size)
     n_all = int(sum(tiles)) * h * w
     if n_all >= 1 << 32:
         raise ValueError(f"a pooled fit over {n_all} pixels exceeds the 2^32 the native counters hold; fit on a subset of the tiles")

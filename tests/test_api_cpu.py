@@ -35,12 +35,19 @@ def test_library_exports_every_declared_symbol():
     # which form of the Macenko transform a call takes (host logic only): wide pixels in big batches of mid-sized tiles
     takes = _native.require().sx_macenko_takes_two_pass
     f32, u8, bf16 = _native.DTYPE_CODES[torch.float32], _native.DTYPE_CODES[torch.uint8], _native.DTYPE_CODES[torch.bfloat16]
-    assert takes(f32, 64, 512, 512, 0) == 1 and takes(_native.DTYPE_CODES[torch.float64], 64, 512, 512, 0) == 1
+    assert takes(f32, 64, 512, 512, 0) == 1 and takes(_native.DTYPE_CODES[torch.float64], 64, 512, 512, 0) == 0      # (float64: the four passes)
     assert takes(f32, 1, 512, 512, 0) == 0 and takes(f32, 4, 2048, 2048, 0) == 0 and takes(f32, 1024, 64, 64, 0) == 0 and takes(f32, 1024, 128, 128, 0) == 0
     assert takes(u8, 64, 512, 512, 0) == 1 and takes(bf16, 64, 384, 384, 0) == 1      # narrow pixels: tiles of ~360 x 360 ... 512 x 512 (round 3: dense candidate records)
     assert takes(bf16, 256, 224, 224, 0) == 0 and takes(u8, 164, 320, 320, 0) == 0 and takes(u8, 36, 724, 724, 0) == 0 and takes(u8, 4, 512, 512, 0) == 0
     assert takes(f32, 64, 512, 512, _native.MACENKO_CLASSIC) == 0 and takes(f32, 64, 512, 512, _native.MACENKO_SAMPLED) == 0
-    assert takes(u8, 4, 128, 128, _native.MACENKO_TWO_PASS) == 1 and takes(f32, 1, 8, 8, _native.MACENKO_TWO_PASS) == 0
+    # the diagnostic build's flag forces the two-pass form wherever it is able to run; the product library knows no such flag
+    takes_d = _native.require_diag().sx_macenko_takes_two_pass
+    assert takes_d(u8, 4, 128, 128, _native.MACENKO_TWO_PASS) == 1 and takes_d(f32, 1, 8, 8, _native.MACENKO_TWO_PASS) == 0
+    assert takes(u8, 4, 128, 128, _native.MACENKO_TWO_PASS) == 0
+    # six public flag bits; the diagnostic ones are declared only under SX_DIAG
+    public = re.findall(r"^#define (SX_MACENKO_[A-Z0-9_]+) (\d+)u", header.split("#ifdef SX_DIAG")[0], flags=re.M)
+    assert sorted(name for name, _ in public if name != "SX_MACENKO_PARAM_FLOATS") == ["SX_MACENKO_CHANNELS_LAST", "SX_MACENKO_CLASSIC", "SX_MACENKO_NORMALIZE_0_1", "SX_MACENKO_OUT_BF16",
+                                                                                     "SX_MACENKO_OUT_F16", "SX_MACENKO_SAMPLED"]
 
 
 def test_public_surface():

@@ -184,3 +184,42 @@ def test_cached_tile_counts_are_checked_collectively(tmp_path, packed):
         np.testing.assert_allclose(r["mc2"], mc4, rtol=2e-5)
         np.testing.assert_array_equal(r["he3"], r["he2"])
     np.testing.assert_array_equal(r0["he2"], r1["he2"])
+
+
+def _emptied_worker(rank: int, world_size: int, port: int, out_dir: str, packed: bool):
+    """after a cached call, rank 1's shard shrinks to NO tile.  Rank 1 reads fresh counts and knows; rank 0 trusts its cache and
+    goes on into the stage exchanges.  Nobody may be left alone in a collective: both ranks end with the ValueError."""
+    from tests._numpy_steps import NumpyMacenkoBracketSteps, NumpyMacenkoPackedSteps
+
+    Steps = NumpyMacenkoPackedSteps if packed else NumpyMacenkoBracketSteps
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        sxd._TILE_COUNTS.clear()
+        tiles = synth.he_batch(5, 48, 48, seed0=31)
+        sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:5], steps=Steps())
+        cached = len(sxd._TILE_COUNTS)
+        raised = ""
+        try:
+            sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[5:5], steps=Steps())      # rank 1: no tile now
+        except ValueError as exc:
+            raised = str(exc)
+        # ... and the process group is still usable afterwards (no rank is stuck in a collective): one more ordinary fit
+        again = sxd.macenko_fit_pooled(tiles[:3] if rank == 0 else tiles[3:5], steps=Steps())
+        np.savez(os.path.join(out_dir, f"emptied{rank}.npz"), raised=raised, cached=cached, he=again[0].numpy())
+    finally:
+        sxd._TILE_COUNTS.clear()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("packed", [False, True])
+def test_a_shard_that_shrinks_to_no_tile_raises_on_every_rank(tmp_path, packed):
+    mp.spawn(_emptied_worker, args=(2, _free_port(), str(tmp_path), packed), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "emptied0.npz"), np.load(tmp_path / "emptied1.npz")
+    assert int(r0["cached"]) == 1      # (rank 0 did take its counts on trust in the second call)
+    for r in (r0, r1):
+        assert "at least one tile" in str(r["raised"]), str(r["raised"])
+    np.testing.assert_array_equal(r0["he"], r1["he"])
+    he5, _ = so.macenko_fit(synth.he_batch(5, 48, 48, seed0=31).numpy(), signs="positive_sum")
+    np.testing.assert_allclose(r0["he"], he5, atol=2e-5)

@@ -29,7 +29,7 @@ def dev():
 def be(dev):
     from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
-    return MacenkoHIP(dev)
+    return MacenkoHIP(dev, diag=True)      # the diagnostic build: its flags force the forms and the rare paths
 
 
 def _same(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -38,7 +38,7 @@ def _same(a: torch.Tensor, b: torch.Tensor) -> bool:
 
 def _three(be, x, extra=0, **kw):
     n, _, h, w = x.shape
-    lib = _native.require()
+    lib = _native.require_diag()
     assert lib.sx_macenko_form(F32, n, h, w, FUSED | extra) == 2, "not a fused-form shape"
     assert lib.sx_macenko_form(F32, n, h, w, _native.MACENKO_TWO_PASS | extra) == 1
     fused = be.transform(x, SM, TMC, _extra_flags=FUSED | extra, **kw)
@@ -152,7 +152,7 @@ def test_fused_replays_from_a_graph_on_new_data(be, dev):
 
 def test_workspace_sizes_per_form():
     """a call is checked against what ITS form needs."""
-    lib = _native.require()
+    lib = _native.require_diag()
     mb = 1 << 20
     bf16, u8 = _native.DTYPE_CODES[torch.bfloat16], _native.DTYPE_CODES[torch.uint8]
     assert lib.sx_macenko_workspace_bytes_for(bf16, 256, 224, 224, 0) <= 60 * mb
@@ -170,7 +170,7 @@ def test_router_does_not_synchronise_the_host(dev):
     the only two ways the backend could read device memory synchronously."""
     from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
-    fresh = MacenkoHIP(dev)
+    fresh = MacenkoHIP(dev, diag=True)
     x = synth.as_dtype(synth.he_batch(16, 512, 512, seed0=900), torch.float32).to(dev)
     sm, tmc = SM.to(dev), TMC.to(dev)
     ref = fresh.transform(x, sm, tmc, _extra_flags=_native.MACENKO_CLASSIC)

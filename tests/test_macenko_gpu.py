@@ -165,6 +165,9 @@ def test_bracket_fallback_path_is_exact(dev):
     blocky = tile[:, :, ::512, ::256].repeat_interleave(512, dim=2).repeat_interleave(256, dim=3).contiguous()
     from stainx_amd import _native
 
+    from stainx_amd.backends.torch_hip_backend import MacenkoHIP
+
+    be = MacenkoHIP(dev, diag=True)      # (the flag below exists in the diagnostic build only)
     for x in (blocky, synth.as_dtype(blocky, torch.float32)):
         # (the tie shortcut would resolve these brackets from their counts: switched off to reach the slow path)
         out = be.transform(x.to(dev), torch.from_numpy(ref_he), torch.from_numpy(ref_mc), _extra_flags=_native.MACENKO_NO_TIE_SHORTCUT)

@@ -81,7 +81,7 @@ def test_workspace_contents_never_reach_the_result(dev, hw):
     x = synth.as_dtype(synth.he_batch(3, *hw, seed0=31), torch.float32).to(dev)
     sm, tmc = torch.tensor(synth.HE_REF).to(dev), torch.tensor([1.9705, 1.0308]).to(dev)
     for precision, flags in (("stable", _native.MACENKO_CLASSIC), ("stable", _native.MACENKO_TWO_PASS), ("sampled", 0)):
-        be = MacenkoHIP(dev, precision=precision)
+        be = MacenkoHIP(dev, precision=precision, diag=bool(flags & _native.MACENKO_DIAG_BITS))
         first = be.transform(x, sm, tmc, _extra_flags=flags)
         ws = be.last_workspace
         for fill in (0xFF, 0x00, 0x7F):

@@ -93,7 +93,7 @@ def test_real_quadrants_in_every_form(dev, real):
     from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
     _, g, quads, _ = real
-    be = MacenkoHIP(dev)
+    be = MacenkoHIP(dev, diag=True)      # (two of the forms below exist in the diagnostic build only; the product's forms are the same code there)
     sm, tmc = torch.from_numpy(g["stain_matrix"]), torch.from_numpy(g["target_max_conc"])
     stride = (512 * 512) // 4096
     for name, dt in (("f32", torch.float32), ("u8", torch.uint8)):

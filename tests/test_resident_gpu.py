@@ -27,7 +27,7 @@ def dev():
 def be(dev):
     from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
-    return MacenkoHIP(dev)
+    return MacenkoHIP(dev, diag=True)      # the diagnostic build: its flags force the forms and the rare paths
 
 
 SM = torch.tensor(synth.HE_REF, dtype=torch.float32)

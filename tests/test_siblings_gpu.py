@@ -73,6 +73,27 @@ def test_reinhard_config1_fit_transform_vs_oracle(dev):
     assert np.abs(solo.astype(int) - got[:1].astype(int)).max() > 1      # batch-coupled, like the reference
 
 
+@pytest.mark.parametrize("shape", [(3, 30, 30), (2, 33, 47), (1, 17, 20), (4, 50, 50), (1, 5, 4)])
+def test_reinhard_partial_last_sweep(dev, shape):
+    """the colour matrices run on the matrix core (v_mfma_f32_4x4x1 ignores the execution mask and reads its matrix column from
+    all four lanes of a block), so a sweep in which some lanes of a block have no pixels left must still give every live lane its
+    result: tiles whose pixel count is not a multiple of a wave's 256 (16-byte packs: 900, 2500 pixels) or of four (1551, 340: the
+    scalar path), fit and transform against the oracle."""
+    from stainx_amd import Reinhard
+
+    n, h, w = shape
+    ref = synth.as_dtype(synth.noise_u8((1, 3, h, w), 142), torch.float32)
+    src_u8 = synth.noise_u8((n, 3, h, w), 143)
+    mean, std = so.reinhard_fit(ref.numpy())
+    for dt, tol in ((torch.float32, 1e-4), (torch.uint8, 1)):
+        src = synth.as_dtype(src_u8, dt)
+        norm = Reinhard(device=dev, backend="torch_hip").fit(ref.to(dev))
+        np.testing.assert_allclose(norm._reference_mean.cpu().numpy(), mean, atol=2e-3)
+        got = norm.transform(src.to(dev)).cpu().numpy()
+        want = so.reinhard_transform(src.numpy(), mean, std)
+        assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= tol, (shape, dt)
+
+
 # ------------------------------------------------------------------ histogram matching
 def test_histogram_matching_matches_reference_golden(dev, golden):
     from stainx_amd.backends.torch_hip_backend import HistogramMatchingHIP
@@ -219,8 +240,8 @@ def test_histogram_matching_ready_workspace_calls(dev):
 
 def test_reinhard_ready_workspace_calls(dev):
     """include/stainx_hip.h, sx_reinhard_transform_ready: the transform without the launch that clears the arrival counters.  Same bits
-    as the plain call; a workspace that was not ready is noticed; the backend re-initialises its workspace when the shape changes (the
-    counters lie where the shape puts them)."""
+    as the plain call; a workspace that was not ready is noticed; calls of different shapes may alternate on one ready workspace (the
+    counters lie at a place the shape does not move)."""
     from stainx_amd import _native
     from stainx_amd.backends.torch_hip_backend import ReinhardHIP
 
@@ -253,6 +274,19 @@ def test_reinhard_ready_workspace_calls(dev):
     assert status() & 1
     assert lib.sx_reinhard_workspace_init(ws.data_ptr(), ws.numel(), stream) == 0
     assert torch.equal(run(lib.sx_reinhard_transform_ready), want) and status() == 0
+    # shapes alternate on ONE ready workspace through the C ABI, no init in between (the arrival counters used to lie behind the
+    # partial sums, i.e. where the SHAPE put them -- a call of one shape left its sums where the other shape's counters are)
+    shapes = [src, src[:2, :, :64, :96].contiguous(), src[:5, :, :200, :200].contiguous(), src[:1].contiguous()]
+
+    def run_on(x, fn):
+        out = torch.empty_like(x)
+        assert fn(x.data_ptr(), out.data_ptr(), f32, x.shape[0], x.shape[2], x.shape[3], mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel(), stream) == 0
+        return out
+
+    wants = [run_on(x, lib.sx_reinhard_transform) for x in shapes]
+    for _ in range(2):
+        for x, w_ in zip(shapes + shapes[::-1], wants + wants[::-1]):
+            assert torch.equal(run_on(x, lib.sx_reinhard_transform_ready), w_) and status() == 0, tuple(x.shape)
     # the backend: shapes alternate on one workspace, a fit in between
     small = src[:2, :, :64, :96].contiguous()
     want_small = be.transform(small, mean, std)

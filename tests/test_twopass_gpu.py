@@ -25,7 +25,7 @@ def dev():
 def be(dev):
     from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
-    return MacenkoHIP(dev)
+    return MacenkoHIP(dev, diag=True)      # the diagnostic build: its flags force the forms and the rare paths
 
 
 SM = torch.tensor(synth.HE_REF, dtype=torch.float32)
@@ -117,7 +117,7 @@ def test_default_route_and_feedback(be, dev):
     backend leaves it again when the library reports tiles it could not speculate on (here: two white tiles in the batch)."""
     from stainx_amd.backends.torch_hip_backend import MacenkoHIP
 
-    fresh = MacenkoHIP(dev)
+    fresh = MacenkoHIP(dev, diag=True)
     tiles = synth.he_batch(16, 512, 512, seed0=2000)
     x = synth.as_dtype(tiles, torch.float32).to(dev)
     out = fresh.transform(x, SM, TMC)
@@ -138,7 +138,7 @@ def test_default_route_and_feedback(be, dev):
     assert _same(first, classic)
     # calls the library runs in its four-pass form anyway (small batches, narrow pixels on small tiles) take no part in the feedback:
     # no event, no side-stream copy (7 us of host time on a launch-bound call)
-    quiet = MacenkoHIP(dev)
+    quiet = MacenkoHIP(dev, diag=True)
     quiet.transform(x[:1].contiguous(), SM, TMC)
     quiet.transform(synth.as_dtype(tiles[:8], torch.uint8).to(dev), SM, TMC)
     quiet.transform(synth.as_dtype(synth.he_batch(96, 224, 224, seed0=5), torch.bfloat16).to(dev), SM, TMC)
