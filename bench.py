@@ -52,8 +52,8 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 COPY_CEILING_GBS = 6290.0      # MI355X_MICROARCH.md: measured float4 copy
-TRAFFIC_FILE = ROOT / "profiles" / "r03_macenko_cfg2_hbm_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/hbm_traffic.py
-KERNEL_STATS = "profiles/r03_macenko_cfg2_kernel_stats.txt"
+TRAFFIC_FILE = ROOT / "profiles" / "r04_macenko_cfg2_hbm_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/hbm_traffic.py
+KERNEL_STATS = "profiles/r04_macenko_cfg2_kernel_stats.txt"
 TILES, HEIGHT, WIDTH = 64, 512, 512
 BYTES_PER_PIXEL = 24           # fp32 in + fp32 out, 3 channels
 

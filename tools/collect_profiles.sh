@@ -11,6 +11,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 python3 $R/bench.py --workload fit_transform_pooled --steps 200 --warmup 20 > $O/bench_pooled.json 2> $O/bench_pooled.err
+export STAINX_BENCH_NO_REAL=1      # the traces below are the headline's launches only (the default line's real-tile record runs other forms)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu --steps 300 --warmup 50 > $O/kt.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu --steps 20 --warmup 5 > $O/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu --steps 20 --warmup 5 > $O/pmc_write.log 2>&1
