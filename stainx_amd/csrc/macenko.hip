@@ -145,6 +145,7 @@ struct alignas(256) PoolState {
     uint32_t rank_in_bin[kSlots], range[kSlots][2];
     uint32_t ok[kSlots], overflow;     // overflow bit s: a tile's candidate buffer overflowed in slot s
     uint32_t status;                   // distributed fit: non-zero when a bracket did not hold (the caller falls back to the radix rounds)
+    uint32_t arrived;                  // distributed fit: workgroups of the gather launch that have moved their candidates (the last one closes the rank's record)
     uint32_t compact[kSlots][kCompact];
 };
 
@@ -2120,7 +2121,12 @@ __global__ __launch_bounds__(512) void pool_reduce_kernel(Geometry g, Workspace 
 
 // (2) one workgroup per tile: every workgroup scans the pooled histogram for the bin holding the wanted rank (the same
 // answer everywhere), then moves its tile's candidates of that bin to the compact list
-__global__ __launch_bounds__(kGroupThreads) void pool_gather_kernel(Geometry g, Workspace ws, int stage) {
+// Distributed fit (sx_macenko_pfit_gather_packed): `sums` are the counts added up over all ranks (the layout of
+// pfit_reduce_export_kernel) and take the place of the pool's local sums -- what a separate import launch did --, and `row_out` is
+// the rank's stage record [count, count, stale flag | 2 x share keys]: the candidates go there as well as to the pool's list, and the
+// workgroup that arrives last writes the two counts and the flag -- what a separate export launch did.
+__global__ __launch_bounds__(kGroupThreads) void pool_gather_kernel(Geometry g, Workspace ws, int stage, const long long* __restrict__ sums = nullptr, const int* __restrict__ stale_flag = nullptr,
+                                                                    uint32_t* __restrict__ row_out = nullptr, int share = 0) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[2][256];
     constexpr int kLocal = 2048;
     __shared__ uint32_t range[2][2], live[2], local_n[2], local_base[2];
@@ -2137,13 +2143,19 @@ __global__ __launch_bounds__(kGroupThreads) void pool_gather_kernel(Geometry g, 
 #pragma unroll
         for (int u = 0; u < kPrefetchCand; ++u) pre[j][u] = get(&cand[u * kGroupThreads + threadIdx.x]);
     }
-    if (threadIdx.x < 512) (&hist[0][0])[threadIdx.x] = get(&(&pool->hist[stage][0][0])[threadIdx.x]);
+    if (threadIdx.x < 512) (&hist[0][0])[threadIdx.x] = sums ? (uint32_t)sums[stage * 512 + threadIdx.x] : get(&(&pool->hist[stage][0][0])[threadIdx.x]);
     __syncthreads();
     if (wave < 2) {
         const int slot = 2 * stage + wave;
-        const uint32_t ncand = get(&pool->ncand[slot]), below = get(&pool->below[slot]);
+        const uint32_t ncand = sums ? (uint32_t)sums[1024 + kSlots + slot] : get(&pool->ncand[slot]), below = sums ? (uint32_t)sums[1024 + slot] : get(&pool->below[slot]);
+        const uint32_t overflow = sums ? (sums[1024 + 2 * kSlots] ? 0xFu : 0u) : get(&pool->overflow);
         const unsigned long long rank = get(&st0.rank[slot]);
-        const bool ok = ((get(&pool->overflow) >> slot) & 1u) == 0 && rank >= below && rank - below < ncand;
+        const bool ok = ((overflow >> slot) & 1u) == 0 && rank >= below && rank - below < ncand;
+        if (sums && tile == 0 && lane_id() == 0) {      // (the group stage reads these from the pool)
+            put(&pool->ncand[slot], ncand);
+            put(&pool->below[slot], below);
+            if (wave == 0) put(&pool->overflow, overflow);
+        }
         uint32_t b = 0, rb = 0, first = 1, last = 0;
         if (ok) {
             scan_pick32(hist[wave], (uint32_t)(rank - below), b, rb);
@@ -2177,6 +2189,7 @@ __global__ __launch_bounds__(kGroupThreads) void pool_gather_kernel(Geometry g, 
             } else {      // more than the LDS list holds (degenerate data): straight to the pooled list
                 const uint32_t g_at = atomicAdd(&pool->compact_n[slot], 1u);
                 if (g_at < (uint32_t)kCompact) put(&pool->compact[slot][g_at], k);
+                if (row_out && g_at < (uint32_t)share) row_out[3 + (size_t)j * share + g_at] = k;
             }
         };
 #pragma unroll
@@ -2199,8 +2212,20 @@ __global__ __launch_bounds__(kGroupThreads) void pool_gather_kernel(Geometry g, 
     for (int j = 0; j < 2; ++j) {
         if (!live[j]) continue;
         const uint32_t m = min(local_n[j], (uint32_t)kLocal), base = local_base[j];
-        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
             if (base + i < (uint32_t)kCompact) put(&pool->compact[2 * stage + j][base + i], local[j][i]);
+            if (row_out && base + i < (uint32_t)share) row_out[3 + (size_t)j * share + base + i] = local[j][i];
+        }
+    }
+    if (row_out) {      // the record's head: by the workgroup that arrives last (one counter add per workgroup)
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(&pool->arrived, 1u) == (uint32_t)g.n_tiles - 1u) {
+            row_out[0] = atomicAdd(&pool->compact_n[2 * stage], 0u);
+            row_out[1] = atomicAdd(&pool->compact_n[2 * stage + 1], 0u);
+            row_out[2] = stale_flag ? (uint32_t)stale_flag[0] : 0u;
+            atomicExch(&pool->arrived, 0u);
+        }
     }
 }
 
@@ -2693,6 +2718,20 @@ static int run_estimate(const T* images, const Geometry& g, const Workspace& ws,
 template <typename T, int V, bool kInter = false>
 static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws, const float* tmc, hipStream_t stream, void* key_scratch = nullptr) {
     const unsigned n = (unsigned)g.n_tiles, grid = (unsigned)(g.n_tiles * g.blocks_per_tile);
+#ifndef SX_DIAG
+    // The product library builds the two-pass form for what its default serves: whole 16-byte packs (V > 1) and the dense candidate
+    // records (tiles up to 512 x 512) -- sx_macenko_form() and transform_typed() send everything else to the four passes.  The
+    // per-wave candidate segments, the scalar pass A and the unaligned prior (0.9 MB of code) are in the diagnostic build only.
+    if constexpr (V == 1) {
+        return fail(SX_ERR_BAD_ARG, "the two-pass form needs 16-byte aligned tiles of whole packs");
+    } else {
+        if (!g.dense) return fail(SX_ERR_BAD_ARG, "the two-pass form serves tiles of up to 512 x 512 pixels in this build");
+        hipLaunchKernelGGL((prior_kernel<T, true, kInter>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
+        hipLaunchKernelGGL((pass_a_kernel<T, V, kInter, true>), dim3(grid), dim3(kStreamThreads), 0, stream, images, g, ws);
+        hipLaunchKernelGGL((estimate_stage_kernel<T, true>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc, static_cast<uint32_t*>(key_scratch));
+        return check_launch("macenko two-pass estimate");
+    }
+#else
     const bool quads = (g.pixels % 4 == 0) && aligned_for(images, 4 * sizeof(T));
     if (quads)
         hipLaunchKernelGGL((prior_kernel<T, true, kInter>), dim3(n), dim3(kGroupThreads), 0, stream, images, g, ws);
@@ -2706,6 +2745,7 @@ static int run_two_pass(const T* images, const Geometry& g, const Workspace& ws,
         hipLaunchKernelGGL((estimate_stage_kernel<T>), dim3(2 * n), dim3(kGroupThreads), 0, stream, images, g, ws, tmc, static_cast<uint32_t*>(key_scratch));
     }
     return check_launch("macenko two-pass estimate");
+#endif
 }
 
 #ifdef SX_DIAG
@@ -2852,6 +2892,9 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
         g.fused = 0;
         g.two_pass = 0;
     }
+#ifndef SX_DIAG
+    if (g.two_pass && !vec) g.two_pass = 0;      // (unaligned pointers: the four passes serve them; their workspace is a prefix of the two-pass one)
+#endif
     if (g.two_pass) {
         g.dense = (fused_size(g.pixels) && !g.fused) ? 1 : 0;
         g.spec_kw = kSpecKw;
@@ -2983,15 +3026,53 @@ __global__ __launch_bounds__(kGroupThreads) void pfit_plane_kernel(Geometry g, W
     plane_stage<float>(nullptr, g, ws, 0, 0, &sh, moments);      // no fallback in a fit: the pixels are never touched
 }
 
-__global__ void pfit_export_sums_kernel(Workspace ws, long long* __restrict__ sums_out) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(ws.pool);
-    for (int i = threadIdx.x; i < kPoolSums; i += blockDim.x) {
-        uint32_t v;
-        if (i < 1024) v = src[i];
-        else if (i < 1024 + kSlots) v = ws.pool->below[i - 1024];
-        else if (i < 1024 + 2 * kSlots) v = ws.pool->ncand[i - 1024 - kSlots];
-        else v = ws.pool->overflow;
-        sums_out[i] = (long long)v;
+// A stage's work-item histograms and per-tile counters added up over the rank's tiles, straight into the record the all-reduce takes
+// (what pool_reduce_kernel + pfit_export_sums_kernel did in two launches through the pool): workgroup b adds bins 16 b ... 16 b + 15 of
+// the stage's 512 over all work items (16 lanes of items per bin), workgroup 0 also the counters.  The other stage's entries are
+// zero (nobody reads them); the pooled candidate lists of the stage start empty.
+constexpr int kReduceBins = 16, kReduceLanes = 16;
+__global__ __launch_bounds__(kReduceBins * kReduceLanes) void pfit_reduce_export_kernel(Geometry g, Workspace ws, int stage, long long* __restrict__ sums_out) {
+    __shared__ uint32_t part[kReduceLanes][kReduceBins];
+    const int bin = blockIdx.x * kReduceBins + (threadIdx.x % kReduceBins), lane = threadIdx.x / kReduceBins;
+    const int64_t items = g.n_tiles * g.blocks_per_tile;
+    const uint32_t* src = ws.block_hist + bin;
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (int64_t r = lane; r < items; r += kReduceLanes) sum += get(&src[(size_t)r * 512]);
+    part[lane][threadIdx.x % kReduceBins] = sum;
+    __syncthreads();
+    if (threadIdx.x < kReduceBins) {
+        unsigned long long total = 0;
+#pragma unroll
+        for (int l = 0; l < kReduceLanes; ++l) total += part[l][threadIdx.x];
+        sums_out[stage * 512 + bin] = (long long)total;
+        sums_out[(1 - stage) * 512 + bin] = 0;
+    }
+    if (blockIdx.x == 0) {
+        __shared__ unsigned long long below_s[2], ncand_s[2];
+        __shared__ uint32_t over_s;
+        if (threadIdx.x < 2) below_s[threadIdx.x] = ncand_s[threadIdx.x] = 0ull;
+        if (threadIdx.x == 0) over_s = get(&ws.pool->overflow);
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < 2 * g.n_tiles; i += blockDim.x) {
+            const int j = (int)(i & 1), slot = 2 * stage + j;
+            const int64_t tile = i >> 1;
+            const uint32_t n = get(&ws.state[tile].ncand[slot]), b = get(&ws.state[tile].below[slot]);
+            if (b) atomicAdd(&below_s[j], (unsigned long long)b);
+            atomicAdd(&ncand_s[j], (unsigned long long)min(n, g.cap));
+            if (n > g.cap) atomicOr(&over_s, 1u << slot);
+        }
+        __syncthreads();
+        if (threadIdx.x < kSlots) {
+            const int slot = threadIdx.x, j = slot - 2 * stage;
+            sums_out[1024 + slot] = (j == 0 || j == 1) ? (long long)below_s[j] : 0;
+            sums_out[1024 + kSlots + slot] = (j == 0 || j == 1) ? (long long)ncand_s[j] : 0;
+        }
+        if (threadIdx.x == 0) {
+            sums_out[1024 + 2 * kSlots] = (long long)over_s;
+            put(&ws.pool->compact_n[2 * stage], 0u);
+            put(&ws.pool->compact_n[2 * stage + 1], 0u);
+        }
     }
 }
 
@@ -3061,23 +3142,22 @@ struct PfitRanks {
 // every rank's stats record -> the moments added up in rank order, the union sample (every world-th column of every rank's sample,
 // ranks one after the other, cut at 4096; what stainx_amd/distributed.py assembled with slices), and "some rank's tile count is not
 // the one the host took on trust"
-__global__ __launch_bounds__(256) void pfit_unpack_stats_kernel(Workspace ws, const unsigned char* __restrict__ gathered, PfitRanks ranks, const long long* __restrict__ expected_tiles, int* __restrict__ stale_out,
-                                                                double* __restrict__ moments_out) {
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < kPartial) {
-            double s = 0.0;
-            for (int r = 0; r < ranks.world; ++r) s += reinterpret_cast<const double*>(gathered + (size_t)r * kPfitStatsRecord + 8)[threadIdx.x];
-            moments_out[threadIdx.x] = s;
-        }
-        if (threadIdx.x == 64 && stale_out) {
-            int stale = 0;
-            if (expected_tiles)
-                for (int r = 0; r < ranks.world; ++r) stale |= reinterpret_cast<const long long*>(gathered + (size_t)r * kPfitStatsRecord)[0] != expected_tiles[r];
-            stale_out[0] = stale;
-        }
-        return;
+// (the prologue of the plane stage's one workgroup: 12 sample values per thread, then the barrier behind which the stage reads them)
+__global__ __launch_bounds__(kGroupThreads) void pfit_plane_packed_kernel(Geometry g, Workspace ws, const unsigned char* __restrict__ gathered, PfitRanks ranks, const long long* __restrict__ expected_tiles,
+                                                                          int* __restrict__ stale_out, double* __restrict__ moments_out) {
+    __shared__ TileScratch sh;
+    if (threadIdx.x < kPartial) {
+        double s = 0.0;
+        for (int r = 0; r < ranks.world; ++r) s += reinterpret_cast<const double*>(gathered + (size_t)r * kPfitStatsRecord + 8)[threadIdx.x];
+        moments_out[threadIdx.x] = s;
     }
-    for (int i = (blockIdx.x - 1) * blockDim.x + threadIdx.x; i < 3 * kSample; i += (gridDim.x - 1) * blockDim.x) {
+    if (threadIdx.x == 64 && stale_out) {
+        int stale = 0;
+        if (expected_tiles)
+            for (int r = 0; r < ranks.world; ++r) stale |= reinterpret_cast<const long long*>(gathered + (size_t)r * kPfitStatsRecord)[0] != expected_tiles[r];
+        stale_out[0] = stale;
+    }
+    for (int i = threadIdx.x; i < 3 * kSample; i += blockDim.x) {
         const int ch = i / kSample, pos = i % kSample;
         float v = 0.0f;
         int base = 0;
@@ -3091,20 +3171,13 @@ __global__ __launch_bounds__(256) void pfit_unpack_stats_kernel(Workspace ws, co
         }
         ws.sample_od[i] = v;
     }
-}
-
-// the rank's stage record: counts, the stale flag, its candidates of the picked bin
-__global__ void pfit_export_row_kernel(Workspace ws, int stage, int share, const int* __restrict__ stale_flag, unsigned* __restrict__ row_out) {
-    for (int j = 0; j < 2; ++j) {
-        const uint32_t n = ws.pool->compact_n[2 * stage + j];
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < min(n, (uint32_t)share); i += gridDim.x * blockDim.x) row_out[3 + (size_t)j * share + i] = ws.pool->compact[2 * stage + j][i];
-        if (blockIdx.x == 0 && threadIdx.x == 0) row_out[j] = n;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) row_out[2] = stale_flag ? (unsigned)stale_flag[0] : 0u;
+    __syncthreads();
+    plane_stage<float>(nullptr, g, ws, 0, 0, &sh, moments_out);      // no fallback in a fit: the pixels are never touched
 }
 
 // the ranks' stage records, gathered -> the union of the candidates in the pool; any rank's stale flag -> bit 4 of the pool's status
-__global__ void pfit_merge_rows_kernel(Workspace ws, int stage, int world, int share, const unsigned* __restrict__ rows) {
+// (the prologue of the group stage's workgroup: ends with a barrier, behind which the workgroup reads what it wrote)
+__device__ __forceinline__ void pfit_merge_rows(const Workspace& ws, int stage, int world, int share, const unsigned* __restrict__ rows) {
     __shared__ uint32_t base[64][2];
     const size_t stride = 3 + 2 * (size_t)share;
     if (threadIdx.x < 2) {
@@ -3131,6 +3204,23 @@ __global__ void pfit_merge_rows_kernel(Workspace ws, int stage, int world, int s
             for (int i = threadIdx.x; i < n; i += blockDim.x)
                 if (base[r][j] + i < (uint32_t)kCompact) ws.pool->compact[2 * stage + j][base[r][j] + i] = rows[r * stride + 3 + (size_t)j * share + i];
         }
+    __syncthreads();
+}
+
+// The group stage of a distributed fit behind the exchange of the stage records: merge, then the stage itself, in one workgroup
+// (stage 1 also leaves the status word: what pfit_status_kernel does for the unpacked steps).
+__global__ __launch_bounds__(kGroupThreads) void pfit_stain_rows_kernel(Geometry g, Workspace ws, int world, int share, const unsigned* __restrict__ rows) {
+    __shared__ TileScratch sh;
+    pfit_merge_rows(ws, 0, world, share, rows);
+    stain_stage<float, true>(nullptr, g, ws, 0, &sh);
+}
+__global__ __launch_bounds__(kGroupThreads) void pfit_scale_rows_kernel(Geometry g, Workspace ws, int world, int share, const unsigned* __restrict__ rows, float* __restrict__ he_out, float* __restrict__ max_c_out,
+                                                                        int* __restrict__ status_out) {
+    __shared__ TileScratch sh;
+    pfit_merge_rows(ws, 1, world, share, rows);
+    scale_stage<float, true>(nullptr, g, ws, 0, nullptr, he_out, max_c_out, &sh);
+    __syncthreads();
+    if (threadIdx.x == 0) status_out[0] = (int)(atomicOr(&ws.pool->status, 0u) | (atomicOr(&ws.state[0].fell_back, 0u) & 0xFu));
 }
 
 // ---- distributed pooled fit: staged entry points (host does the all-reduces in between) -----------
@@ -3190,8 +3280,7 @@ static int pfit_pass_typed(const void* images, const Geometry& g0, const Workspa
         if (vec) hipLaunchKernelGGL((bracket_kernel<T, W, true>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
         else hipLaunchKernelGGL((bracket_kernel<T, 1, true>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, ws);
     }
-    hipLaunchKernelGGL(pool_reduce_kernel, dim3((unsigned)g.n_tiles), dim3(512), 0, stream, g, ws, stage);
-    hipLaunchKernelGGL(pfit_export_sums_kernel, dim3(1), dim3(256), 0, stream, ws, sums_out);
+    hipLaunchKernelGGL(pfit_reduce_export_kernel, dim3(512 / kReduceBins), dim3(kReduceBins * kReduceLanes), 0, stream, g, ws, stage, sums_out);
     return check_launch("macenko pfit pass");
 }
 
@@ -3244,6 +3333,9 @@ extern "C" int sx_macenko_form(int dtype, int64_t n, int64_t h, int64_t w, unsig
     const bool pays = n * pixels >= (1ll << 22) && (wide ? (pixels >= 36864 && pixels <= (1ll << 19)) : (pixels >= 131072 && pixels <= 262144));
     const bool wanted = forced_two_pass != 0 || (pays && !(flags & SX_MACENKO_CLASSIC));
     if (!(wanted && two_pass_size(pixels))) return 0;
+#ifndef SX_DIAG
+    if (!fused_size(pixels)) return 0;      // (the product build carries the two-pass form with dense candidate records only: tiles up to 512 x 512)
+#endif
     const bool fusable = fuse != 0 && dtype == SX_F32 && fused_size(pixels) && !(flags & SX_MACENKO_CHANNELS_LAST);
     return fusable ? 2 : 1;
 }
@@ -3483,8 +3575,7 @@ extern "C" int sx_macenko_pfit_plane_packed(const void* gathered, int world, con
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     double* moments = reinterpret_cast<double*>(ws.pool->compact[kSlots - 1] + kCompact - 32);      // (scratch: the tail of the last compact list, free until the second stage's merge)
-    hipLaunchKernelGGL(pfit_unpack_stats_kernel, dim3(13), dim3(256), 0, stream, ws, static_cast<const unsigned char*>(gathered), ranks, expected_tiles, stale_out, moments);
-    hipLaunchKernelGGL(pfit_plane_kernel, dim3(1), dim3(kGroupThreads), 0, stream, g, ws, moments);
+    hipLaunchKernelGGL(pfit_plane_packed_kernel, dim3(1), dim3(kGroupThreads), 0, stream, g, ws, static_cast<const unsigned char*>(gathered), ranks, expected_tiles, stale_out, moments);
     return check_launch("macenko pfit plane (packed)");
 }
 
@@ -3496,9 +3587,9 @@ extern "C" int sx_macenko_pfit_gather_packed(const long long* sums_global, int s
     const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
-    hipLaunchKernelGGL(pfit_import_sums_kernel, dim3(1), dim3(256), 0, stream, ws, sums_global, stage);
-    hipLaunchKernelGGL(pool_gather_kernel, dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, g, ws, stage);
-    hipLaunchKernelGGL(pfit_export_row_kernel, dim3(8), dim3(256), 0, stream, ws, stage, share, stale_flag, row_out);
+    // (one launch: the global sums are read where they lie and the record is written by the workgroups that find its keys --
+    // pfit_reduce_export_kernel has emptied the stage's pooled lists)
+    hipLaunchKernelGGL(pool_gather_kernel, dim3((unsigned)g.n_tiles), dim3(kGroupThreads), 0, stream, g, ws, stage, sums_global, stale_flag, row_out, share);
     return check_launch("macenko pfit gather (packed)");
 }
 
@@ -3511,13 +3602,10 @@ extern "C" int sx_macenko_pfit_finish_packed(const unsigned* gathered_rows, int 
     const Geometry g = pfit_geometry(n, h, w, n_all, sample_count);
     const Workspace ws = carve(ws_ptr, n, g.pixels);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
-    hipLaunchKernelGGL(pfit_merge_rows_kernel, dim3(1), dim3(1024), 0, stream, ws, stage, world, share, gathered_rows);
-    if (stage == 0) {
-        hipLaunchKernelGGL((stain_kernel<float, true>), dim3(1), dim3(kGroupThreads), 0, stream, (const float*)nullptr, g, ws);
-    } else {
-        hipLaunchKernelGGL((scale_kernel<float, true>), dim3(1), dim3(kGroupThreads), 0, stream, (const float*)nullptr, g, ws, (const float*)nullptr, he_out, max_c_out);
-        hipLaunchKernelGGL(pfit_status_kernel, dim3(1), dim3(64), 0, stream, ws, status_out);
-    }
+    if (stage == 0)
+        hipLaunchKernelGGL(pfit_stain_rows_kernel, dim3(1), dim3(kGroupThreads), 0, stream, g, ws, world, share, gathered_rows);
+    else
+        hipLaunchKernelGGL(pfit_scale_rows_kernel, dim3(1), dim3(kGroupThreads), 0, stream, g, ws, world, share, gathered_rows, he_out, max_c_out, status_out);
     return check_launch("macenko pfit finish (packed)");
 }
 
