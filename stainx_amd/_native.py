@@ -169,8 +169,38 @@ def check(code: int, what: str, lib=None) -> None:
     raise RuntimeError(msg)      # the reference's TORCH_CHECK failures surface as RuntimeError too
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # the handle itself, without a Stream object (a step of the pooled fit asks ~20 times)
+
+
+def device_index(device: torch.device) -> int:
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
 def stream_ptr(device: torch.device) -> int:
+    """The HIP stream handle of the device's CURRENT torch stream (what every entry point takes as its last argument)."""
+    if _raw_stream is not None:
+        return int(_raw_stream(device_index(device)))
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class on_device:
+    """`with on_device(dev):` -- torch.cuda.device(dev) when dev is not already the current device, nothing otherwise (the guard costs
+    several microseconds a time; the host side of a pooled fit step takes it a dozen times)."""
+
+    __slots__ = ("_guard",)
+
+    def __init__(self, device: torch.device):
+        self._guard = None if device_index(device) == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self._guard is not None:
+            self._guard.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._guard is not None:
+            return self._guard.__exit__(*exc)
+        return False
 
 
 class Scratch:
@@ -187,7 +217,7 @@ class Scratch:
         self._retired: list[torch.Tensor] = []
 
     def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
-        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+        key = (device_index(device), stream_ptr(device))
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             if buf is not None:
@@ -199,7 +229,7 @@ class Scratch:
 
     def drop(self, device: torch.device) -> None:
         """Forget the current stream's buffer (after a failed call its state is unknown): the next get() makes a new one."""
-        key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+        key = (device_index(device), stream_ptr(device))
         buf = self._bufs.pop(key, None)
         if buf is not None:
             self._retired.append(buf)

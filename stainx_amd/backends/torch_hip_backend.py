@@ -46,6 +46,7 @@ class TorchHIPBackendBase:
         self._lib = _native.require()
         _native.check_arch(self.device)
         self._scratch = _native.Scratch()
+        self._pfit_bytes: dict[tuple[int, int, int], int] = {}
 
     def _f32(self, t: torch.Tensor) -> torch.Tensor:
         return t.to(device=self.device, dtype=torch.float32).contiguous()
@@ -124,7 +125,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         out = torch.empty(tuple(images.shape), dtype=out_dtype, device=self.device)
         if n == 0 or h * w == 0:
             return out
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             flags = ((_native.MACENKO_NORMALIZE_0_1 if normalize_to_0_1 else 0) | (_native.MACENKO_CHANNELS_LAST if channels_last else 0)
                      | (_native.MACENKO_SAMPLED if self._precision == "sampled" else 0) | int(_extra_flags) | self._env_flags)
             # (only calls the library would run in its two-pass form take part in the feedback: for the others -- small batches,
@@ -211,7 +212,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         n, _, h, w = images.shape
         he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
         max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             nbytes = self._lib.sx_macenko_workspace_bytes_for(_dtype_code(images), n, h, w, _native.MACENKO_CLASSIC)
             ws = self._scratch.get(nbytes, self.device)
             rc = self._lib.sx_macenko_fit(images.data_ptr(), _dtype_code(images), n, h, w, he.data_ptr(), max_c.data_ptr(),
@@ -231,7 +232,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         images = images.contiguous()
         n, _, h, w = images.shape
         mom = torch.empty(20, dtype=torch.float64, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._scratch.get(self._lib.sx_macenko_workspace_bytes_for(_dtype_code(images), n, h, w, _native.MACENKO_CLASSIC), self.device)
             rc = self._lib.sx_macenko_dfit_moments(images.data_ptr(), _dtype_code(images), n, h, w, mom.data_ptr(), ws.data_ptr(), ws.numel(),
                                                    _native.stream_ptr(self.device))
@@ -241,7 +242,7 @@ class MacenkoHIP(TorchHIPBackendBase):
     def dfit_begin(self, moments: torch.Tensor) -> torch.Tensor:
         state = torch.zeros(self._lib.sx_macenko_dfit_state_bytes(), dtype=torch.uint8, device=self.device)
         moments = moments.to(self.device, torch.float64).contiguous()
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             rc = self._lib.sx_macenko_dfit_begin(moments.data_ptr(), state.data_ptr(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_dfit_begin")
         return state
@@ -250,7 +251,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         images = images.to(self.device).contiguous()
         n, _, h, w = images.shape
         hist = torch.empty((2, 256), dtype=torch.int64, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             rc = self._lib.sx_macenko_dfit_histogram(images.data_ptr(), _dtype_code(images), n, h, w, state.data_ptr(), int(stage), hist.data_ptr(),
                                                      _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_dfit_histogram")
@@ -258,21 +259,24 @@ class MacenkoHIP(TorchHIPBackendBase):
 
     def dfit_advance(self, state: torch.Tensor, stage: int, hist: torch.Tensor) -> None:
         hist = hist.to(self.device, torch.int64).contiguous()
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             rc = self._lib.sx_macenko_dfit_advance(state.data_ptr(), int(stage), hist.data_ptr(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_dfit_advance")
 
     def dfit_result(self, state: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
         he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
         max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             rc = self._lib.sx_macenko_dfit_result(state.data_ptr(), he.data_ptr(), max_c.data_ptr(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_dfit_result")
         return he, max_c
 
     # ---- the same pooled fit across ranks on the bracket machinery (three passes; see stainx_amd/distributed.py) ----
     def _pfit_ws(self, n: int, h: int, w: int) -> torch.Tensor:
-        return self._scratch.get(self._lib.sx_macenko_workspace_bytes_for(_native.DTYPE_CODES[torch.float32], n, h, w, _native.MACENKO_CLASSIC), self.device)
+        need = self._pfit_bytes.get((n, h, w))
+        if need is None:
+            need = self._pfit_bytes[(n, h, w)] = int(self._lib.sx_macenko_workspace_bytes_for(_native.DTYPE_CODES[torch.float32], n, h, w, _native.MACENKO_CLASSIC))
+        return self._scratch.get(need, self.device)
 
     def pfit_sample_count(self, n: int, h: int, w: int) -> int:
         return int(self._lib.sx_macenko_pfit_sample_count(n, h, w))
@@ -286,7 +290,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         n, _, h, w = images.shape
         mom = torch.empty(10, dtype=torch.float64, device=self.device)
         sample = torch.empty((3, 4096), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_stats(images.data_ptr(), _dtype_code(images), n, h, w, mom.data_ptr(), sample.data_ptr(), ws.data_ptr(), ws.numel(),
                                                  _native.stream_ptr(self.device))
@@ -298,7 +302,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         n, h, w = shape
         moments = moments.to(self.device, torch.float64).contiguous()
         sample_union = sample_union.to(self.device, torch.float32).contiguous()
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_plane(moments.data_ptr(), int(n_all), sample_union.data_ptr(), int(sample_count), n, h, w, ws.data_ptr(), ws.numel(),
                                                  _native.stream_ptr(self.device))
@@ -308,7 +312,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         images = images.to(self.device).contiguous()
         n, _, h, w = images.shape
         sums = torch.empty(_native.PFIT_SUMS, dtype=torch.int64, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_pass(images.data_ptr(), _dtype_code(images), n, h, w, int(stage), int(n_all), int(sample_count), sums.data_ptr(), ws.data_ptr(),
                                                 ws.numel(), _native.stream_ptr(self.device))
@@ -320,7 +324,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         sums_global = sums_global.to(self.device, torch.int64).contiguous()
         compact = torch.empty((2, int(share)), dtype=torch.int32, device=self.device)      # (only the first `counts` entries of a row are written and read: no fill)
         counts = torch.empty(2, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_gather(sums_global.data_ptr(), int(stage), int(n_all), int(sample_count), n, h, w, int(share), compact.data_ptr(), counts.data_ptr(),
                                                   ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -336,7 +340,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
         max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
         status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_finish(gathered_compact.data_ptr(), gathered_counts.data_ptr(), world, share, int(stage), int(n_all), int(sample_count), n, h, w,
                                                   he.data_ptr(), max_c.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -353,7 +357,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         images = images.contiguous()
         n, _, h, w = images.shape
         record = torch.empty(_native.PFIT_STATS_RECORD_BYTES, dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_stats_packed(images.data_ptr(), _dtype_code(images), n, h, w, record.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_pfit_stats_packed")
@@ -373,7 +377,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         gathered = gathered.contiguous()
         counts = (_c.c_int * world)(*[int(v) for v in sample_counts])
         stale = torch.empty(1, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_plane_packed(gathered.data_ptr(), world, _c.cast(counts, _c.c_void_p), expected_tiles.data_ptr() if expected_tiles is not None else None,
                                                         stale.data_ptr(), int(n_all), int(sample_count), n, h, w, ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -384,7 +388,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         n, h, w = shape
         sums_global = sums_global.to(self.device, torch.int64).contiguous()
         row = torch.empty(3 + 2 * int(share), dtype=torch.int32, device=self.device)      # (only the counted entries are written and read: no fill)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_gather_packed(sums_global.data_ptr(), int(stage), int(n_all), int(sample_count), n, h, w, int(share),
                                                          stale.data_ptr() if stale is not None else None, row.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -399,7 +403,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         he = torch.empty((3, 2), dtype=torch.float32, device=self.device)
         max_c = torch.empty((2,), dtype=torch.float32, device=self.device)
         status = torch.empty(1, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._pfit_ws(n, h, w)
             rc = self._lib.sx_macenko_pfit_finish_packed(gathered_rows.data_ptr(), world, int(share), int(stage), int(n_all), int(sample_count), n, h, w, he.data_ptr(), max_c.data_ptr(),
                                                          status.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -412,7 +416,7 @@ class MacenkoHIP(TorchHIPBackendBase):
         if self.last_workspace is None:
             raise RuntimeError("no transform / fit has run on this backend yet")
         raw = torch.empty((n_groups, _native.MACENKO_PARAM_FLOATS), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             rc = self._lib.sx_macenko_tile_params(self.last_workspace.data_ptr(), n_groups, raw.data_ptr(), _native.stream_ptr(self.device))
         _native.check(rc, "sx_macenko_tile_params")
         raw = raw.cpu()
@@ -455,7 +459,7 @@ class ReinhardHIP(TorchHIPBackendBase):
         n, _, h, w = images.shape
         mean = torch.empty(3, dtype=torch.float32, device=self.device)
         std = torch.empty(3, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._workspace(n, h, w)
             rc = self._lib.sx_reinhard_fit(images.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(), std.data_ptr(),
                                            ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -475,7 +479,7 @@ class ReinhardHIP(TorchHIPBackendBase):
         out = torch.empty_like(images)
         if images.numel() == 0:
             return out
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._workspace(n, h, w, ready=True)
             rc = self._lib.sx_reinhard_transform_ready(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(),
                                                        std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -493,7 +497,7 @@ class ReinhardHIP(TorchHIPBackendBase):
         images = images.contiguous()
         n, _, h, w = images.shape
         sums = torch.empty(6, dtype=torch.float64, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._workspace(n, h, w)
             rc = self._lib.sx_reinhard_sums(images.data_ptr(), _dtype_code(images), n, h, w, sums.data_ptr(), ws.data_ptr(), ws.numel(),
                                             _native.stream_ptr(self.device))
@@ -508,7 +512,7 @@ class ReinhardHIP(TorchHIPBackendBase):
         sums = sums.to(self.device, torch.float64).contiguous()
         n, _, h, w = images.shape
         out = torch.empty_like(images)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._workspace(n, h, w)
             rc = self._lib.sx_reinhard_apply(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, sums.data_ptr(), float(n_total_pixels),
                                              mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -556,7 +560,7 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         images = images.to(self.device).contiguous()
         n, h, w, last = self._dims(images)
         hists = torch.empty((3, 256), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
             rc = self._lib.sx_hm_fit_ready(images.data_ptr(), _dtype_code(images), n, h, w, int(last), hists.data_ptr(), ws.data_ptr(), ws.numel(),
                                            _native.stream_ptr(self.device))
@@ -610,7 +614,7 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         out = torch.empty_like(images)
         if images.numel() == 0:
             return out
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
             rc = self._lib.sx_hm_transform_ready(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, int(last), ref.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
@@ -623,7 +627,7 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         images = images.to(self.device).contiguous()
         n, h, w, last = self._dims(images)
         counts = torch.empty((3, 256), dtype=torch.int64, device=self.device)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
             rc = self._lib.sx_hm_counts_ready(images.data_ptr(), _dtype_code(images), n, h, w, int(last), counts.data_ptr(), ws.data_ptr(), ws.numel(),
                                               _native.stream_ptr(self.device))
@@ -636,7 +640,7 @@ class HistogramMatchingHIP(TorchHIPBackendBase):
         ref = self._stack_reference(reference_histogram, 3)
         counts = counts.to(self.device, torch.int64).contiguous()
         out = torch.empty_like(images)
-        with torch.cuda.device(self.device):
+        with _native.on_device(self.device):
             ws = self._scratch.get(self._lib.sx_hm_workspace_bytes(n, h, w), self.device)
             rc = self._lib.sx_hm_apply(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, int(last), counts.data_ptr(), float(n_total_pixels),
                                        ref.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))

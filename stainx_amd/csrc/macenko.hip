@@ -2218,7 +2218,8 @@ __global__ __launch_bounds__(kGroupThreads) void pool_gather_kernel(Geometry g, 
         }
     }
     if (row_out) {      // the record's head: by the workgroup that arrives last (one counter add per workgroup)
-        __threadfence();
+        // (no fence: the keys are read by the NEXT launch, and the counts the last workgroup reads were added by returning atomics that
+        // every workgroup has waited for before its arrival add -- an agent-scope release here writes the L2 back: 25 us instead of 11)
         __syncthreads();
         if (threadIdx.x == 0 && atomicAdd(&pool->arrived, 1u) == (uint32_t)g.n_tiles - 1u) {
             row_out[0] = atomicAdd(&pool->compact_n[2 * stage], 0u);
