@@ -65,6 +65,8 @@ typedef enum {
 #define SX_MACENKO_FUSE 512u         /* the two-pass form with its last three launches as ONE launch with tile-level dependencies (planar float32 tiles of
                                        128x128 ... 512x512; same bits; slower: DESIGN.md 4c) */
 #define SX_MACENKO_RESIDENT 1024u    /* the tile-resident form: one launch, a tile's pixels kept on chip as 8-bit codes (same bits; slower: DESIGN.md 4e) */
+#define SX_MACENKO_NO_CODES 2048u    /* the four passes over float32 tiles read the float pixels in every pass (by default the first pass leaves 8-bit codes
+                                       of the tiles that consist of grey levels and the later passes read those: same bits) */
 #endif
 
 int sx_version(void);

@@ -30,7 +30,8 @@ MACENKO_SPEC_FAIL = 128
 MACENKO_TWO_PASS = 256
 MACENKO_FUSE = 512
 MACENKO_RESIDENT = 1024
-MACENKO_DIAG_BITS = MACENKO_NO_TIE_SHORTCUT | MACENKO_SPEC_FAIL | MACENKO_TWO_PASS | MACENKO_FUSE | MACENKO_RESIDENT
+MACENKO_NO_CODES = 2048      # diagnostic build: the four passes over float32 tiles without the 8-bit codes
+MACENKO_DIAG_BITS = MACENKO_NO_TIE_SHORTCUT | MACENKO_SPEC_FAIL | MACENKO_TWO_PASS | MACENKO_FUSE | MACENKO_RESIDENT | MACENKO_NO_CODES
 MACENKO_PARAM_FLOATS = 48
 PFIT_STATS_RECORD_BYTES = 49240
 PFIT_SUMS = 1033

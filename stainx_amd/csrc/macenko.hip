@@ -24,6 +24,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <cstdlib>
 
@@ -117,6 +118,7 @@ struct Geometry {
     int dense;                    // two-pass: candidates in dense record arrays (tiles up to 512 x 512) instead of a segment per wave
     uint32_t fused_cap;           // fused: candidate records per tile and slot
     int fused_items;              // fused: pass-A work items of the call (= reconstruct work items)
+    uint32_t code_epoch;          // four passes over float tiles: non-zero = the first pass leaves 8-bit codes, the later passes read them (Coded<F>); the call's number
 };
 
 // Every field named: the struct is filled at half a dozen entry points.
@@ -164,6 +166,8 @@ struct Workspace {
     struct FusedSched* fsched;    // fused transform: the launch's ticket counter and error word
     struct FusedTile* ftile;      // fused transform: per tile, the counters the roles of the launch hand each other work through
     uint4* cand_rec;              // fused transform: [n_tiles][kSlots][fused_cap] candidate records (od0, od1, od2, -)
+    uint32_t* code_bad;           // coded four passes: [n_tiles] the number of the last call whose first pass found a non-8-bit element in the tile
+    uint8_t* codes;               // coded four passes: [n_tiles][3][pixels] grey-level codes (both overlay the areas behind the base level: the four passes use none of them)
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -222,6 +226,9 @@ constexpr size_t kFusedSchedBytes = 512, kFusedTileBytes = 64;
 //   [ two-pass: candidate optical densities, segment fills, key spill ]            + the four-launch two-pass transform
 // sx_macenko_workspace_bytes() is the whole (any call fits); sx_macenko_workspace_bytes_for() the prefix one call needs.
 enum WorkspaceLevel { kWsBase = 0, kWsFused = 1, kWsTwoPass = 2 };
+// coded four passes (float32 tiles of whole 16-pixel packs, batches of at least 2^20 pixels): the codes and the per-tile flags, behind the base level
+static bool coded_size(int64_t n_tiles, int64_t pixels) { return pixels % 16 == 0 && n_tiles * pixels >= (1ll << 20); }
+static size_t coded_bytes(int64_t n_tiles, int64_t pixels) { return align_up(sizeof(uint32_t) * (size_t)n_tiles, 256) + align_up((size_t)3 * pixels * n_tiles, 256); }
 static size_t workspace_bytes(int64_t n_tiles, int64_t pixels, int level = kWsTwoPass) {
     const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
     size_t total = align_up(sizeof(GroupState) * n, 256);
@@ -244,7 +251,8 @@ static size_t workspace_bytes(int64_t n_tiles, int64_t pixels, int level = kWsTw
     return total;
 }
 
-static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
+// codes_at: where the coded passes' area lies (bytes from the base): behind the level of the form the call takes (0: behind the base level)
+static Workspace carve(void* base, int64_t n_tiles, int64_t pixels, size_t codes_at = 0) {
     Workspace w;
     char* p = static_cast<char*>(base);
     const size_t b = (size_t)blocks_per_tile_for(pixels), n = (size_t)n_tiles;
@@ -263,6 +271,11 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels) {
     w.pool = reinterpret_cast<PoolState*>(p);
     p += align_up(sizeof(PoolState), 256);
     // (beyond the base level the pointers are only used by the forms whose workspace level includes them)
+    {
+        char* c = codes_at ? static_cast<char*>(base) + codes_at : p;
+        w.code_bad = reinterpret_cast<uint32_t*>(c);
+        w.codes = reinterpret_cast<uint8_t*>(c + align_up(sizeof(uint32_t) * n, 256));
+    }
     w.prior = reinterpret_cast<PriorRecord*>(p);
     p += align_up(kPriorRecordBytes * n, 256);
     w.fsched = reinterpret_cast<FusedSched*>(p);
@@ -333,6 +346,53 @@ template <> struct LevelTables<uint8_t> {
         __syncthreads();
     }
 };
+// 8-bit CODES of float tiles (round 4).  Image pixels are 8-bit grey levels: a float tile made from a decoded image (u8 / 255: what
+// ToDtype(float32, scale=True), the reference's benchmarks and bench.py produce) holds one of 256 values per channel.  The four-pass
+// form's first pass (stats_item<..., kEmit>) checks that for every element -- x is code k iff its bits are those of F(k / 255) -- and
+// leaves the tile as bytes in the workspace; a tile that passes is read as those bytes by the three later passes (a quarter of the
+// bytes, and the table lookups of uint8 tiles instead of a v_log_f32 per channel), a tile that does not is read as it was.  The codes
+// are a lossless copy and the tables hold the very expressions the float path evaluates, so every pixel gets the bits it got
+// before.  Coded<F> is the element type of such a copy: byte storage (every `sizeof(T) == 1` path applies), F's meaning.
+template <typename F> struct Coded {
+    uint8_t v;
+    __device__ __forceinline__ operator uint32_t() const { return v; }
+};
+template <typename T> struct Sem { using type = T; };                  // what an element MEANS (output rules), as opposed to how it is stored
+template <typename F> struct Sem<Coded<F>> { using type = F; };
+template <typename F> __device__ __forceinline__ float code_value(int k) {      // the float a tile of F holds for grey level k: float(k) / 255 (IEEE), rounded to F
+    return Elem<F>::load(Elem<F>::store(div255_of_level((float)k)));
+}
+template <typename F> struct LevelTables<Coded<F>> {
+    float od[256], l2[256];
+    __device__ __forceinline__ void fill() {
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+            const float v = code_value<F>(t);
+            od[t] = optical_density<F>(v);
+            l2[t] = log2_level<F>(v);
+        }
+        __syncthreads();
+    }
+};
+// The first pass's table: {the bits of code k's float, its optical density}, kCodeCopies bank-striped copies (a lane reads copy
+// lane % kCodeCopies: with one copy half of the LDS pipe's cycles were bank conflicts in the tile-resident kernel).
+// code_pack(): a pack's 3 x V elements -> their codes (one 32-bit word per plane, stored to the tile's code planes), their optical
+// densities, and whether any element of the wave's packs is not a grey level (then: the densities by the expression, the tile marked).
+template <typename F, int kCodeCopies> struct CodeTable {      // (4 copies = 8 KB in the moments pass; 2 in pass A of the two-pass form, whose four workgroups per CU leave 4 KB each)
+    static constexpr int copies = kCodeCopies;
+    uint2 e[256 * kCodeCopies];
+    __device__ __forceinline__ void fill() {
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+            const float v = code_value<F>(t);
+            const uint2 entry = make_uint2(__float_as_uint(v), __float_as_uint(optical_density<F>(v)));
+#pragma unroll
+            for (int c = 0; c < kCodeCopies; ++c) e[t * kCodeCopies + c] = entry;
+        }
+        __syncthreads();
+    }
+};
+// which streaming instantiations carry the coded variant: planar float32 tiles in 16-byte packs
+template <typename T, int V, bool kInter> struct Codable { static constexpr bool value = std::is_same<T, float>::value && V == 4 && !kInter; };
+
 template <typename T> __device__ __forceinline__ float od_of(float v, const LevelTables<T>& tb) {
     if constexpr (sizeof(T) == 1) return tb.od[__float_as_uint(v)]; else return optical_density<T>(v);
 }
@@ -473,6 +533,38 @@ struct PixelPacks {
         }
     }
 };
+
+template <typename T, int V, bool kInter, class Table>
+__device__ __forceinline__ void code_pack(const PixelPacks<T, V, kInter>& u, const LevelTables<T>& tb, const Table& ct, const Geometry& g, const Workspace& ws, int64_t tile, int64_t p, float (&od_pack)[V][3]) {
+    static_assert(V == 4 && !kInter, "a pack of four codes is one 32-bit word of a plane");
+    constexpr int kCodeCopies = Table::copies;
+    uint32_t word[3];
+    uint32_t differ = 0u;
+    const int copy = (int)(threadIdx.x % kCodeCopies);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        word[c] = 0u;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float x = u.value(c, i);
+            const uint32_t k = (uint32_t)__builtin_amdgcn_fmed3f(fmaf(x, 255.0f, 0.5f), 0.0f, 255.5f);      // nearest grey level (anything else fails the comparison below)
+            const uint2 entry = ct.e[k * kCodeCopies + copy];
+            differ |= entry.x ^ __float_as_uint(x);
+            od_pack[i][c] = __uint_as_float(entry.y);
+            word[c] |= k << (8 * i);
+        }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(differ != 0u) != 0ull, 0)) {      // some element of the wave's packs is not an 8-bit level: this tile stays float
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) od_pack[i][c] = od_of<T>(u.value(c, i), tb);
+        if (differ != 0u) put(&ws.code_bad[tile], g.code_epoch);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<uint32_t*>(ws.codes + ((size_t)tile * 3 + c) * g.pixels + p) = word[c];
+}
+
 
 template <typename O, int V, bool kInter>
 __device__ __forceinline__ void store_pixels(O* __restrict__ dst, int64_t pixels, int64_t p, const O (&res)[3][V]) {
@@ -1314,8 +1406,12 @@ __device__ __forceinline__ bool tile_has_three_kept_witnesses(const T* __restric
     return __syncthreads_count(kept) >= 3;
 }
 
-template <typename T, int V, int TPB, bool kInter>
-__device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh, const LevelTables<T>& tb) {
+// kEmit (Codable instantiations, g.code_epoch != 0): the pass also leaves the tile as 8-bit codes (see Coded<F>) -- a pack's elements
+// are looked up in the code table; where all of them are grey levels (the table entry has the element's bits) their optical density
+// comes from the table too, else (wave-uniform branch) from the expression as without kEmit and the tile is marked.
+template <typename T, int V, int TPB, bool kInter, bool kEmit = false>
+__device__ void stats_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, StatsScratch<TPB>* sh, const LevelTables<T>& tb,
+                           const CodeTable<T, 4>* __restrict__ ct = nullptr) {
     const int64_t p_begin = (int64_t)chunk_id * g.chunk;
     const int64_t p_end = min(p_begin + (int64_t)g.chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
@@ -1372,11 +1468,15 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
 #pragma unroll
                 for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od_of<T>(raw[c], tb));
             }
+            float od_pack[kEmit ? V : 1][3];
+            if constexpr (kEmit) code_pack(u, tb, *ct, g, ws, tile, p, od_pack);
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float od[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) od[c] = od_of<T>(u.value(c, i), tb);
+                for (int c = 0; c < 3; ++c) {
+                    if constexpr (kEmit) od[c] = od_pack[i][c]; else od[c] = od_of<T>(u.value(c, i), tb);
+                }
                 if (!by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
                     const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;
                     if ((pos & mask) == sample_offset_in(jj, shift, group_count) && jj < sample_count) {
@@ -1689,17 +1789,18 @@ __device__ __forceinline__ void reconstruct_item(const T* __restrict__ images, O
                 const float x = fmaf(m[c][2], l[2], fmaf(m[c][1], l[1], fmaf(m[c][0], l[0], k[c])));
                 float rgb = __builtin_amdgcn_exp2f(x);                                // bare v_exp_f32: a result below 2^-126 is 0 either way after the cast
                 rgb = fminf(fmaxf(rgb, 0.0f), 255.0f);                                // :459, :128
+                using S = typename Sem<T>::type;      // (the output rules follow what the element means: a coded float tile is a float tile)
                 if constexpr (kUnit) {
                     // cast to the input dtype first, then /255 in that dtype (_template.py:111-112);
                     // u8 promotes to f32 (and, with SX_MACENKO_OUT_*, that f32 is cast once more: `.to(bfloat16)` fused)
-                    if constexpr (sizeof(T) == 1) {
-                        res[c][i] = Elem<O>::store(div255_of_level((float)Elem<T>::store(rgb)));
-                    } else if constexpr (sizeof(T) == 8) {
+                    if constexpr (sizeof(S) == 1) {
+                        res[c][i] = Elem<O>::store(div255_of_level((float)Elem<S>::store(rgb)));
+                    } else if constexpr (sizeof(S) == 8) {
                         res[c][i] = (double)rgb / 255.0;
                     } else {
-                        res[c][i] = Elem<O>::store(div255_of_level(Elem<T>::load(Elem<T>::store(rgb))));      // (clamped to [0, 255] above)
+                        res[c][i] = Elem<O>::store(div255_of_level(Elem<S>::load(Elem<S>::store(rgb))));      // (clamped to [0, 255] above)
                     }
-                } else if constexpr (sizeof(T) == 1 && sizeof(O) == 2) {
+                } else if constexpr (sizeof(S) == 1 && sizeof(O) == 2) {
                     res[c][i] = Elem<O>::store((float)Elem<T>::store(rgb));      // the truncated grey level, exactly representable
                 } else {
                     res[c][i] = Elem<O>::store(rgb);
@@ -2410,6 +2511,14 @@ __global__ __launch_bounds__(kStreamThreads, sizeof(T) <= 2 ? 5 : 1) void stats_
     __shared__ StatsScratch<kStreamThreads> sh;
     __shared__ LevelTables<T> tb;
     tb.fill();
+    if constexpr (Codable<T, V, kInter>::value) {
+        if (g.code_epoch != 0u) {      // (uniform over the launch)
+            __shared__ CodeTable<T, 4> ct;
+            ct.fill();
+            stats_item<T, V, kStreamThreads, kInter, true>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh, tb, &ct);
+            return;
+        }
+    }
     stats_item<T, V, kStreamThreads, kInter>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh, tb);
 }
 
@@ -2419,6 +2528,14 @@ __global__ __launch_bounds__(kStreamThreads) void bracket_kernel(const T* __rest
     const int per_tile = g.fine_chunk ? g.fine_blocks : g.blocks_per_tile;
     __shared__ LevelTables<T> tb;
     tb.fill();
+    if constexpr (Codable<T, V, kInter>::value) {
+        if (g.code_epoch != 0u && get(&ws.code_bad[blockIdx.x / per_tile]) != g.code_epoch) {      // the tile is 8-bit levels: its codes (uniform over the workgroup)
+            __shared__ LevelTables<Coded<T>> ctb;
+            ctb.fill();
+            bracket_item<Coded<T>, 16, kConc, kStreamThreads, false>(reinterpret_cast<const Coded<T>*>(ws.codes), g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, blockIdx.x, &sh, ctb);
+            return;
+        }
+    }
     bracket_item<T, V, kConc, kStreamThreads, kInter>(images, g, ws, blockIdx.x / per_tile, blockIdx.x % per_tile, blockIdx.x, &sh, tb);
 }
 
@@ -2428,6 +2545,14 @@ __global__ __launch_bounds__(kStreamThreads) void reconstruct_kernel(const T* __
     __shared__ LevelTables<T> tb;
     tb.fill();
     const unsigned item = blockIdx.x;      // (measured: reversing the order, so that the work items pass A touched last come first, changes nothing)
+    if constexpr (Codable<T, V, kInter>::value && std::is_same<T, O>::value) {
+        if (g.code_epoch != 0u && get(&ws.code_bad[item / per_tile]) != g.code_epoch) {      // the tile is 8-bit levels: its codes in, the same float pixels out
+            __shared__ LevelTables<Coded<T>> ctb;
+            ctb.fill();
+            reconstruct_item<Coded<T>, O, V, kUnit, kStreamThreads, false>(reinterpret_cast<const Coded<T>*>(ws.codes), out, g, ws, item / per_tile, item % per_tile, stain_matrix, ctb);
+            return;
+        }
+    }
     if constexpr (kInter && V > 1) {
         __shared__ uint4 stage[kStreamThreads * 3];      // 3 KB per wave: store_pixels_staged()
         reconstruct_item<T, O, V, kUnit, kStreamThreads, kInter>(images, out, g, ws, item / per_tile, item % per_tile, stain_matrix, tb, stage);
@@ -2896,6 +3021,7 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
 #ifndef SX_DIAG
     if (g.two_pass && !vec) g.two_pass = 0;      // (unaligned pointers: the four passes serve them; their workspace is a prefix of the two-pass one)
 #endif
+    if (!(vec && !g.interleaved && std::is_same<T, float>::value)) g.code_epoch = 0u;      // (the coded passes: planar float32 tiles in 16-byte packs)
     if (g.two_pass) {
         g.dense = (fused_size(g.pixels) && !g.fused) ? 1 : 0;
         g.spec_kw = kSpecKw;
@@ -3300,13 +3426,31 @@ static int validate_images(const void* images, int64_t n, int64_t h, int64_t w, 
     return SX_OK;
 }
 
+// float32 tiles with their 8-bit codes (Coded<F>): the codes lie behind the workspace level of the form the call takes
+static int form_level(int form, int64_t pixels) { return form == 0 ? kWsBase : (fused_size(pixels) ? kWsFused : kWsTwoPass); }
+static size_t coded_workspace_bytes(int64_t n_tiles, int64_t pixels, int form = 0) {
+    return macenko::workspace_bytes(n_tiles, pixels, form_level(form, pixels)) + macenko::coded_bytes(n_tiles, pixels);
+}
+static bool coded_call(int dtype, int64_t n, int64_t pixels, unsigned flags) {
+    return dtype == SX_F32 && macenko::coded_size(n, pixels) && !(flags & (SX_MACENKO_CHANNELS_LAST | SX_MACENKO_SAMPLED));
+}
+// The number of a coded call: what its first pass writes into a tile's flag word when the tile is not 8-bit levels.  Never zero, never
+// the number of another call in this process -- a flag word left by an earlier call (or never written) means nothing to this one.
+static uint32_t next_code_epoch() {
+    static std::atomic<uint32_t> counter{0x5F3759DFu};
+    uint32_t e = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+    if (e == 0u) e = counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+    return e;
+}
+
 extern "C" size_t sx_macenko_workspace_bytes(int64_t n_tiles, int64_t height, int64_t width) {
     if (n_tiles <= 0 || height <= 0 || width <= 0) return 0;
+    size_t need = macenko::workspace_bytes(n_tiles, height * width);
+    if (macenko::coded_size(n_tiles, height * width)) need += macenko::coded_bytes(n_tiles, height * width);
 #ifdef SX_DIAG
-    return std::max(macenko::workspace_bytes(n_tiles, height * width), macenko::resident_bytes(n_tiles, height * width));
-#else
-    return macenko::workspace_bytes(n_tiles, height * width);
+    need = std::max(need, macenko::resident_bytes(n_tiles, height * width));
 #endif
+    return need;
 }
 
 // Which form sx_macenko_transform takes for a call: 0 the four passes, 1 the two-pass form as four launches, 2 the two-pass form
@@ -3355,7 +3499,11 @@ extern "C" size_t sx_macenko_workspace_bytes_for(int dtype, int64_t n_tiles, int
     // (the four-launch two-pass form keeps its candidates in the dense record arrays too for tiles up to 512 x 512: only larger
     // tiles need the per-wave segments)
     const bool dense = form != 0 && fused_size(height * width);
-    return macenko::workspace_bytes(n_tiles, height * width, form == 0 ? kWsBase : (dense ? kWsFused : kWsTwoPass));
+    size_t need = macenko::workspace_bytes(n_tiles, height * width, form == 0 ? kWsBase : (dense ? kWsFused : kWsTwoPass));
+    // (float32 batches: room for the tiles' 8-bit codes, 3 bytes per pixel -- also where the call itself takes the two-pass form: a
+    // caller that sends it to the four passes with SX_MACENKO_CLASSIC on real tissue uses the same buffer)
+    if (coded_call(dtype, n_tiles, height * width, flags)) need = std::max(need, coded_workspace_bytes(n_tiles, height * width, form == 1 ? 1 : 0));
+    return need;
 }
 
 extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, int64_t n, int64_t h, int64_t w, const float* sm, const float* tmc, unsigned flags, void* ws_ptr, size_t ws_bytes, void* stream_ptr) {
@@ -3386,7 +3534,17 @@ extern "C" int sx_macenko_transform(const void* images, void* out, int dtype, in
 #endif
     g.two_pass = form != 0 ? 1 : 0;
     g.fused = form == 2 ? 1 : 0;
-    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    // the four passes over a batch of float32 tiles: 8-bit codes behind the first pass (a workspace sized by an older rule just runs without)
+    // (the two-pass form: its one pass over the input leaves them, its reconstruct pass reads them)
+    size_t codes_at = 0;
+    if ((form == 0 || form == 1) && coded_call(dtype, n, g.pixels, flags) && ws_bytes >= coded_workspace_bytes(n, g.pixels, form)) {
+        g.code_epoch = next_code_epoch();
+        codes_at = macenko::workspace_bytes(n, g.pixels, form_level(form, g.pixels));
+    }
+#ifdef SX_DIAG
+    if (flags & SX_MACENKO_NO_CODES) g.code_epoch = 0u;
+#endif
+    const Workspace ws = carve(ws_ptr, n, g.pixels, codes_at);
     switch (dtype) {
         case SX_U8: return transform_typed<uint8_t>(images, out, g, ws, sm, tmc, unit, stream);
         case SX_F16: return transform_typed<__half>(images, out, g, ws, sm, tmc, unit, stream);

@@ -630,8 +630,11 @@ __device__ __forceinline__ void write_records_fused(const uint32_t (*__restrict_
     }
 }
 
-template <typename T, int V, int TPB, bool kInter, bool kFused = false>
-__device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, PassAScratch<TPB>* sh, const LevelTables<T>& tb) {
+// kEmit: the pass also leaves the tile as 8-bit codes for the reconstruct pass to read (Coded<F>, code_pack() in macenko.hip): the
+// optical densities of a pack of grey levels then come from the code table instead of three v_log_f32 per pixel.
+template <typename T, int V, int TPB, bool kInter, bool kFused = false, bool kEmit = false>
+__device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const Geometry& g, const Workspace& ws, int64_t tile, int chunk_id, int64_t item, PassAScratch<TPB>* sh, const LevelTables<T>& tb,
+                                            const CodeTable<T, 2>* __restrict__ ct = nullptr) {
     const int64_t p_begin = (int64_t)chunk_id * g.chunk;
     const int64_t p_end = min(p_begin + (int64_t)g.chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
@@ -695,6 +698,10 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
             if (p_next < p_end) next.load(img, g.pixels, p_next);
             uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
             asm volatile("" : "+s"(live_mask));      // (opaque: otherwise the comparison behind it is redone for every pixel of the pack -- a 64-bit add and a 64-bit compare each time)
+            float od_pack[kEmit ? V : 1][3];
+            if constexpr (kEmit) {
+                if (live) code_pack(u, tb, *ct, g, ws, tile, base_p + mine, od_pack);
+            }
 #pragma unroll
             for (int i0 = 0; i0 < V; i0 += G) {
                 float od[G][3];
@@ -703,7 +710,9 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
 #pragma unroll
                 for (int gi = 0; gi < G; ++gi) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) od[gi][c] = od_of<T>(u.value(c, i0 + gi), tb);
+                    for (int c = 0; c < 3; ++c) {
+                        if constexpr (kEmit) od[gi][c] = od_pack[i0 + gi][c]; else od[gi][c] = od_of<T>(u.value(c, i0 + gi), tb);
+                    }
                     const bool sel = od_selected(od[gi], false);
                     valid[gi] = __builtin_amdgcn_ballot_w64(sel) & live_mask;      // (the ballot of a bare comparison is the comparison's own mask; of `live && sel` it is a 0 / 1 register compared with 0 again)
                     // (the lanes of `valid` as the branch's mask: `live && sel` made the compiler work `live` out again for every pixel --
@@ -850,10 +859,18 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
 // and run on 20 work items per 512 x 512 tile, all 1280 resident, the call takes 156.9 us against 156.6 us at four waves and 16
 // items; tools/ab_items.py on a debug build.)
 template <typename T, int V, bool kInter = false, bool kDense = false>
-__global__ __launch_bounds__(kStreamThreads) void pass_a_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
+__global__ __launch_bounds__(kStreamThreads, (Codable<T, V, kInter>::value ? 4 : 1)) void pass_a_kernel(const T* __restrict__ images, Geometry g, Workspace ws) {
     __shared__ PassAScratch<kStreamThreads> sh;
     __shared__ LevelTables<T> tb;
     tb.fill();
+    if constexpr (Codable<T, V, kInter>::value) {
+        if (g.code_epoch != 0u) {      // (uniform over the launch)
+            __shared__ CodeTable<T, 2> ct;
+            ct.fill();
+            pass_a_item<T, V, kStreamThreads, kInter, kDense, true>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh, tb, &ct);
+            return;
+        }
+    }
     pass_a_item<T, V, kStreamThreads, kInter, kDense>(images, g, ws, blockIdx.x / g.blocks_per_tile, blockIdx.x % g.blocks_per_tile, blockIdx.x, &sh, tb);
 }
 
