@@ -482,8 +482,9 @@ def main() -> None:
                          "device_ms_median": round(sorted(step_ms)[len(step_ms) // 2], 4),
                          "device_ms_hot": round(sum(hot_ms) / len(hot_ms), 4),
                          "device_ms_hot_note": "the same call over ONE input buffer (201 MB: it stays in the 256 MiB Infinity Cache between calls), what the reference's harness would time",
-                         "dominant_kernel": {"name": "reconstruct_kernel", "algorithmic_bytes": pixels * BYTES_PER_PIXEL,
-                                             "note": f"the only launch that moves the full 24 B/px; its rocprofv3 average is in {KERNEL_STATS}"}},
+                         "dominant_kernel": {"name": "pass_a_kernel", "algorithmic_bytes": pixels * 12,
+                                             "note": "the call's one pass over the fp32 input (12 B/px read; it also leaves the tiles as 8-bit codes, 3 B/px, which the "
+                                                     f"reconstruct pass reads instead of the floats before it writes 12 B/px); rocprofv3 averages of all four launches in {KERNEL_STATS}"}},
             "kernel_source_hash": source_hash(),
         }
         if not os.environ.get("STAINX_BENCH_NO_REAL"):

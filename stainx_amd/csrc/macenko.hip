@@ -534,11 +534,14 @@ struct PixelPacks {
     }
 };
 
+__device__ __forceinline__ void store_codes(const Geometry& g, const Workspace& ws, int64_t tile, int64_t p, const uint32_t (&word)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<uint32_t*>(ws.codes + ((size_t)tile * 3 + c) * g.pixels + p) = word[c];
+}
 template <typename T, int V, bool kInter, class Table>
-__device__ __forceinline__ void code_pack(const PixelPacks<T, V, kInter>& u, const LevelTables<T>& tb, const Table& ct, const Geometry& g, const Workspace& ws, int64_t tile, int64_t p, float (&od_pack)[V][3]) {
+__device__ __forceinline__ void code_pack(const PixelPacks<T, V, kInter>& u, const LevelTables<T>& tb, const Table& ct, const Geometry& g, const Workspace& ws, int64_t tile, float (&od_pack)[V][3], uint32_t (&word)[3]) {
     static_assert(V == 4 && !kInter, "a pack of four codes is one 32-bit word of a plane");
     constexpr int kCodeCopies = Table::copies;
-    uint32_t word[3];
     uint32_t differ = 0u;
     const int copy = (int)(threadIdx.x % kCodeCopies);
 #pragma unroll
@@ -547,7 +550,9 @@ __device__ __forceinline__ void code_pack(const PixelPacks<T, V, kInter>& u, con
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const float x = u.value(c, i);
-            const uint32_t k = (uint32_t)__builtin_amdgcn_fmed3f(fmaf(x, 255.0f, 0.5f), 0.0f, 255.5f);      // nearest grey level (anything else fails the comparison below)
+            // nearest grey level: 255 x + 2^23 has it in the low bits of its mantissa (round to nearest even; an x outside [0, 1] or a
+            // NaN leaves some other byte there, and the comparison below fails)
+            const uint32_t k = __float_as_uint(fmaf(x, 255.0f, 8388608.0f)) & 0xFFu;
             const uint2 entry = ct.e[k * kCodeCopies + copy];
             differ |= entry.x ^ __float_as_uint(x);
             od_pack[i][c] = __uint_as_float(entry.y);
@@ -558,11 +563,13 @@ __device__ __forceinline__ void code_pack(const PixelPacks<T, V, kInter>& u, con
 #pragma unroll
         for (int i = 0; i < V; ++i)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) od_pack[i][c] = od_of<T>(u.value(c, i), tb);
+            for (int c = 0; c < 3; ++c) {
+                float x = u.value(c, i);
+                asm volatile("" : "+v"(x));      // (a real branch: without this the twelve logarithms are computed for every pack and selected away)
+                od_pack[i][c] = od_of<T>(x, tb);
+            }
         if (differ != 0u) put(&ws.code_bad[tile], g.code_epoch);
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) *reinterpret_cast<uint32_t*>(ws.codes + ((size_t)tile * 3 + c) * g.pixels + p) = word[c];
 }
 
 
@@ -1469,7 +1476,11 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
                 for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od_of<T>(raw[c], tb));
             }
             float od_pack[kEmit ? V : 1][3];
-            if constexpr (kEmit) code_pack(u, tb, *ct, g, ws, tile, p, od_pack);
+            if constexpr (kEmit) {
+                uint32_t word[3];
+                code_pack(u, tb, *ct, g, ws, tile, od_pack, word);
+                store_codes(g, ws, tile, p, word);
+            }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float od[3];

@@ -700,7 +700,14 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
             asm volatile("" : "+s"(live_mask));      // (opaque: otherwise the comparison behind it is redone for every pixel of the pack -- a 64-bit add and a 64-bit compare each time)
             float od_pack[kEmit ? V : 1][3];
             if constexpr (kEmit) {
-                if (live) code_pack(u, tb, *ct, g, ws, tile, base_p + mine, od_pack);
+                // (the pass moves 201 MB in and 34 MB of candidate records out at ~5 TB/s; the 50 MB of codes cost what 50 MB cost at that
+                // rate, 46 -> 55 us -- 49 us with the stores left out, and no cheaper with the stores held back until just before the next
+                // pack's request (59 us) or with conflict-free table copies: the reconstruct pass gets 20 us back)
+                if (live) {
+                    uint32_t word[3];
+                    code_pack(u, tb, *ct, g, ws, tile, od_pack, word);
+                    store_codes(g, ws, tile, base_p + mine, word);
+                }
             }
 #pragma unroll
             for (int i0 = 0; i0 < V; i0 += G) {
