@@ -206,6 +206,10 @@ int sx_macenko_pfit_finish_packed(const unsigned* gathered_records_dev, int worl
  * Replaces stainx_cuda_torch.reinhard (bindings.cpp:32) with the numerics of ReinhardTorch
  * (torch_backend.py:304-355): LAB statistics pooled over the whole batch, unbiased std. */
 size_t sx_reinhard_workspace_bytes(int64_t n_tiles, int64_t height, int64_t width);
+/* ... with room for the 8-bit codes of a float32 batch (+ 3 bytes per pixel): sx_reinhard_transform(_ready) then leaves the tiles that
+ * consist of grey levels (float(k) / 255 in every element) as bytes in its first pass and reads those in its second -- same bits, a
+ * quarter of the second pass's input.  Every entry point also accepts the smaller workspace above and then runs without. */
+size_t sx_reinhard_workspace_bytes_for(int dtype, int64_t n_tiles, int64_t height, int64_t width);
 int sx_reinhard_fit(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
                     float* mean_out_dev, float* std_out_dev, void* workspace_dev, size_t workspace_bytes,
                     void* stream);

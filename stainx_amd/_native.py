@@ -71,6 +71,7 @@ SIGNATURES = {
     "sx_macenko_pfit_gather_packed": (_int, [_vp, _int, _c.c_longlong, _int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "sx_macenko_pfit_finish_packed": (_int, [_vp, _int, _int, _int, _c.c_longlong, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sx_reinhard_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "sx_reinhard_workspace_bytes_for": (_sz, [_int, _i64, _i64, _i64]),
     "sx_reinhard_sums": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sx_reinhard_apply": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _vp, _c.c_double, _vp, _vp, _vp, _sz, _vp]),
     "sx_hm_counts": (_int, [_vp, _int, _i64, _i64, _i64, _int, _vp, _vp, _sz, _vp]),

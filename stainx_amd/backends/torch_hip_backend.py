@@ -439,15 +439,17 @@ class ReinhardHIP(TorchHIPBackendBase):
         if images.dim() != 4 or images.shape[1] != 3:
             raise ValueError(f"Reinhard expects NCHW images with C=3, got shape {tuple(images.shape)}")
 
-    def _workspace(self, n: int, h: int, w: int, ready: bool = False) -> torch.Tensor:
+    def _workspace(self, n: int, h: int, w: int, ready: bool = False, code: int | None = None) -> torch.Tensor:
         """The stream's workspace.  Its arrival counters lie where (n, h, w) puts them and are zero between calls OF THAT SHAPE: the
         transform uses the entry point that relies on it (include/stainx_hip.h: sx_reinhard_transform_ready) and has the workspace
         zero-filled first whenever the last call on it had another shape (or there was none)."""
-        ws = self._scratch.get(self._lib.sx_reinhard_workspace_bytes(n, h, w), self.device)
+        # (`code`: the transform's element type -- a float32 batch gets room for its tiles' 8-bit codes behind the workspace proper)
+        base = int(self._lib.sx_reinhard_workspace_bytes(n, h, w))
+        ws = self._scratch.get(base if code is None else int(self._lib.sx_reinhard_workspace_bytes_for(code, n, h, w)), self.device)
         shapes = self.__dict__.setdefault("_ws_shape", {})
         key = (int(n), int(h), int(w))
-        if ready and shapes.get(ws.data_ptr()) != key:
-            _native.check(self._lib.sx_reinhard_workspace_init(ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device)), "sx_reinhard_workspace_init")
+        if ready and shapes.get(ws.data_ptr()) != key:      # (the workspace proper: the codes behind it need no clearing)
+            _native.check(self._lib.sx_reinhard_workspace_init(ws.data_ptr(), base, _native.stream_ptr(self.device)), "sx_reinhard_workspace_init")
         shapes[ws.data_ptr()] = key
         self.last_workspace = ws
         return ws
@@ -486,7 +488,7 @@ class ReinhardHIP(TorchHIPBackendBase):
         if images.numel() == 0:
             return out
         with _native.on_device(self.device):
-            ws = self._workspace(n, h, w, ready=True)
+            ws = self._workspace(n, h, w, ready=True, code=_dtype_code(images))
             rc = self._lib.sx_reinhard_transform_ready(images.data_ptr(), out.data_ptr(), _dtype_code(images), n, h, w, mean.data_ptr(),
                                                        std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(self.device))
         if rc != 0:

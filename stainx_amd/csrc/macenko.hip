@@ -390,7 +390,10 @@ template <typename F, int kCodeCopies> struct CodeTable {      // (4 copies = 8 
         __syncthreads();
     }
 };
-// which streaming instantiations carry the coded variant: planar float32 tiles in 16-byte packs
+// which streaming instantiations carry the coded variant
+// Planar float32 tiles in 16-byte packs.  (bfloat16 / float16 tiles were built and measured too -- code_quad() and store_codes() serve their
+// packs of eight -- and do not pay: their passes are bound by instructions and per-item latency, not by bytes.  256 x 224 x 224 bf16:
+// moments pass 23.8 -> 34.4 us, bracket passes 23.6 + 21.9 -> 24.3 + 22.3 us, reconstruct 26.1 -> 22.0 us; the call 127 -> 140 us.)
 template <typename T, int V, bool kInter> struct Codable { static constexpr bool value = std::is_same<T, float>::value && V == 4 && !kInter; };
 
 template <typename T> __device__ __forceinline__ float od_of(float v, const LevelTables<T>& tb) {
@@ -534,39 +537,49 @@ struct PixelPacks {
     }
 };
 
-__device__ __forceinline__ void store_codes(const Geometry& g, const Workspace& ws, int64_t tile, int64_t p, const uint32_t (&word)[3]) {
+template <int W>      // W 32-bit words of codes per plane: the V = 4 W pixels of a pack
+__device__ __forceinline__ void store_codes(const Geometry& g, const Workspace& ws, int64_t tile, int64_t p, const uint32_t (&word)[3][W]) {
+    static_assert(W == 1 || W == 2, "four or eight codes per plane");
 #pragma unroll
-    for (int c = 0; c < 3; ++c) *reinterpret_cast<uint32_t*>(ws.codes + ((size_t)tile * 3 + c) * g.pixels + p) = word[c];
+    for (int c = 0; c < 3; ++c) {
+        uint8_t* dst = ws.codes + ((size_t)tile * 3 + c) * g.pixels + p;
+        if constexpr (W == 1) *reinterpret_cast<uint32_t*>(dst) = word[c][0]; else *reinterpret_cast<uint2*>(dst) = make_uint2(word[c][0], word[c][1]);
+    }
 }
+// Four pixels of a pack (i0 ... i0 + 3: one 32-bit word of codes per plane) at a time: twelve optical densities live, not 3 V (a pack of
+// eight bf16 / f16 pixels at once spilled the moments pass and pass A to scratch).
 template <typename T, int V, bool kInter, class Table>
-__device__ __forceinline__ void code_pack(const PixelPacks<T, V, kInter>& u, const LevelTables<T>& tb, const Table& ct, const Geometry& g, const Workspace& ws, int64_t tile, float (&od_pack)[V][3], uint32_t (&word)[3]) {
-    static_assert(V == 4 && !kInter, "a pack of four codes is one 32-bit word of a plane");
+__device__ __forceinline__ void code_quad(const PixelPacks<T, V, kInter>& u, int i0, const LevelTables<T>& tb, const Table& ct, const Geometry& g, const Workspace& ws, int64_t tile, float (&od_quad)[4][3], uint32_t (&word)[3][V / 4]) {
+    static_assert((V == 4 || V == 8) && !kInter, "a pack's codes are one or two 32-bit words of a plane");
     constexpr int kCodeCopies = Table::copies;
     uint32_t differ = 0u;
     const int copy = (int)(threadIdx.x % kCodeCopies);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        word[c] = 0u;
+        uint32_t w = 0u;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const float x = u.value(c, i);
+        for (int ii = 0; ii < 4; ++ii) {
+            const float x = u.value(c, i0 + ii);
             // nearest grey level: 255 x + 2^23 has it in the low bits of its mantissa (round to nearest even; an x outside [0, 1] or a
-            // NaN leaves some other byte there, and the comparison below fails)
+            // NaN leaves some other byte there, and the comparison below fails).  bfloat16 tiles: x = k / 255 rounded to eight bits is off
+            // by at most k 2^-9 < 0.5 after the multiplication -- still level k, and 256 different values (1 / 255 exceeds the format's
+            // spacing below 1)
             const uint32_t k = __float_as_uint(fmaf(x, 255.0f, 8388608.0f)) & 0xFFu;
             const uint2 entry = ct.e[k * kCodeCopies + copy];
             differ |= entry.x ^ __float_as_uint(x);
-            od_pack[i][c] = __uint_as_float(entry.y);
-            word[c] |= k << (8 * i);
+            od_quad[ii][c] = __uint_as_float(entry.y);
+            w |= k << (8 * ii);
         }
+        word[c][i0 / 4] = w;
     }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(differ != 0u) != 0ull, 0)) {      // some element of the wave's packs is not an 8-bit level: this tile stays float
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(differ != 0u) != 0ull, 0)) {      // some element of the wave's quads is not an 8-bit level: this tile stays float
 #pragma unroll
-        for (int i = 0; i < V; ++i)
+        for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float x = u.value(c, i);
-                asm volatile("" : "+v"(x));      // (a real branch: without this the twelve logarithms are computed for every pack and selected away)
-                od_pack[i][c] = od_of<T>(x, tb);
+                float x = u.value(c, i0 + ii);
+                asm volatile("" : "+v"(x));      // (a real branch: without this the logarithms are computed for every pack and selected away)
+                od_quad[ii][c] = od_of<T>(x, tb);
             }
         if (differ != 0u) put(&ws.code_bad[tile], g.code_epoch);
     }
@@ -1444,7 +1457,7 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
     // two-byte pixels, and a wave that waits for the load it just issued leaves the vector ALU to the three or four others)
     // Two-byte pixels only (64 x 512 x 512 bf16 in this form 145 -> 141 us): float32 / float64 are bound by the read either way, and
     // the uint8 kernel has no registers to spare for a second set of packs (256 x 224 x 224 uint8 107.5 -> 111 us with it).
-    constexpr bool kAhead = sizeof(T) == 2;
+    constexpr bool kAhead = sizeof(T) == 2 && !kEmit;
     PixelPacks<T, V, kInter> ahead;
     ahead.clear();
     if (kAhead && p_begin + (int64_t)threadIdx.x * V < p_end) ahead.load(img, g.pixels, p_begin + (int64_t)threadIdx.x * V);
@@ -1475,18 +1488,19 @@ __device__ void stats_item(const T* __restrict__ images, const Geometry& g, cons
 #pragma unroll
                 for (int c = 0; c < 3; ++c) put(&sample_out[c * kSample + j], od_of<T>(raw[c], tb));
             }
-            float od_pack[kEmit ? V : 1][3];
+            float od_quad[4][3];
             if constexpr (kEmit) {
-                uint32_t word[3];
-                code_pack(u, tb, *ct, g, ws, tile, od_pack, word);
-                store_codes(g, ws, tile, p, word);
+                static_assert(!kEmit || V == 4, "one quad per pack");
+                uint32_t word[3][1];
+                code_quad(u, 0, tb, *ct, g, ws, tile, od_quad, word);
+                store_codes<1>(g, ws, tile, p, word);
             }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float od[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    if constexpr (kEmit) od[c] = od_pack[i][c]; else od[c] = od_of<T>(u.value(c, i), tb);
+                    if constexpr (kEmit) od[c] = od_quad[i % 4][c]; else od[c] = od_of<T>(u.value(c, i), tb);
                 }
                 if (!by_pack) {      // tiny tiles: stride < V, every pixel looks for itself
                     const uint32_t pos = gpos + (uint32_t)i, jj = pos >> shift;

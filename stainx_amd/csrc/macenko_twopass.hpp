@@ -698,15 +698,16 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
             if (p_next < p_end) next.load(img, g.pixels, p_next);
             uint64_t live_mask = __builtin_amdgcn_ballot_w64(live);
             asm volatile("" : "+s"(live_mask));      // (opaque: otherwise the comparison behind it is redone for every pixel of the pack -- a 64-bit add and a 64-bit compare each time)
-            float od_pack[kEmit ? V : 1][3];
-            if constexpr (kEmit) {
-                // (the pass moves 201 MB in and 34 MB of candidate records out at ~5 TB/s; the 50 MB of codes cost what 50 MB cost at that
-                // rate, 46 -> 55 us -- 49 us with the stores left out, and no cheaper with the stores held back until just before the next
-                // pack's request (59 us) or with conflict-free table copies: the reconstruct pass gets 20 us back)
+            // (kEmit: the pass moves 201 MB in and 34 MB of candidate records out at ~5 TB/s; the 50 MB of codes cost what 50 MB cost at that
+            // rate, 46 -> 55 us -- 49 us with the stores left out, and no cheaper with the stores held back until just before the next
+            // pack's request (59 us) or with conflict-free table copies: the reconstruct pass gets 20 us back)
+            float od_quad[4][3];
+            if constexpr (kEmit) {      // (the whole pack in front of the pixel loop: looked up quad by quad inside it, the pass took 61 us instead of 54)
+                static_assert(!kEmit || V == 4, "one quad per pack");
                 if (live) {
-                    uint32_t word[3];
-                    code_pack(u, tb, *ct, g, ws, tile, od_pack, word);
-                    store_codes(g, ws, tile, base_p + mine, word);
+                    uint32_t word[3][1];
+                    code_quad(u, 0, tb, *ct, g, ws, tile, od_quad, word);
+                    store_codes<1>(g, ws, tile, base_p + mine, word);
                 }
             }
 #pragma unroll
@@ -718,7 +719,7 @@ __device__ __forceinline__ void pass_a_item(const T* __restrict__ images, const 
                 for (int gi = 0; gi < G; ++gi) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        if constexpr (kEmit) od[gi][c] = od_pack[i0 + gi][c]; else od[gi][c] = od_of<T>(u.value(c, i0 + gi), tb);
+                        if constexpr (kEmit) od[gi][c] = od_quad[(i0 + gi) % 4][c]; else od[gi][c] = od_of<T>(u.value(c, i0 + gi), tb);
                     }
                     const bool sel = od_selected(od[gi], false);
                     valid[gi] = __builtin_amdgcn_ballot_w64(sel) & live_mask;      // (the ballot of a bare comparison is the comparison's own mask; of `live && sel` it is a 0 / 1 register compared with 0 again)

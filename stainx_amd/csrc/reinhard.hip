@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstddef>
+#include <type_traits>
 
 namespace sx {
 namespace reinhard {
@@ -55,6 +56,37 @@ struct LinearTable {
         for (int t = threadIdx.x; t < 256; t += blockDim.x) lin[t] = srgb_to_linear(Elem<uint8_t>::load((uint8_t)t));
         __syncthreads();
     }
+};
+
+// 8-bit CODES of float32 tiles (round 4; the Macenko transform's Coded<F>, macenko.hip): a float tile made from a decoded image holds
+// float(k) / 255 for a grey level k in every element.  The statistics pass checks that for every element -- table entry k holds the
+// bits of float(k) / 255 and its linear-light value -- and leaves the tile as bytes behind the workspace; the apply pass reads a tile
+// that passed as those bytes (a quarter of the input bytes; the table instead of a logarithm and an exponential per channel) and a
+// tile that did not as floats.  The table holds the very expression of srgb_to_linear(): every pixel gets the bits it got before.
+constexpr int kCodeCopies = 4;      // bank-striped copies of the statistics pass's table (a lane reads copy lane % 4)
+struct CodeLinTable {
+    uint2 e[256 * kCodeCopies];     // {bits of float(k) / 255, bits of its linear-light value}
+    __device__ __forceinline__ void fill() {
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+            const float v = div255_of_level((float)t);
+            const uint2 entry = make_uint2(__float_as_uint(v), __float_as_uint(srgb_to_linear(v)));
+#pragma unroll
+            for (int c = 0; c < kCodeCopies; ++c) e[t * kCodeCopies + c] = entry;
+        }
+        __syncthreads();
+    }
+};
+struct UnitLinearTable {            // the apply pass's table for coded float tiles: linear light of float(k) / 255
+    float lin[256];
+    __device__ __forceinline__ void fill() {
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) lin[t] = srgb_to_linear(div255_of_level((float)t));
+        __syncthreads();
+    }
+};
+struct Codes {                      // where a call keeps them (null / 0: the call runs without)
+    uint8_t* planes;                // [n_tiles][3][pixels]
+    unsigned int* bad;              // [n_tiles]: the number of the last call whose statistics pass found a non-grey-level element in the tile
+    unsigned int epoch;             // this call's number (never 0)
 };
 
 // The two 3 x 3 colour matrices on the matrix core: a matrix-vector product per pixel is nine multiply-adds on the vector ALU, or three
@@ -131,15 +163,9 @@ __device__ __forceinline__ void f_to_e(const float f[3], float e[3]) {
 
 // e (see above) of the V pixels of the loaded packs: the linear-light values through the table for uint8 (u holds grey levels), through
 // the formula otherwise (unit values); then the matrix for the whole pack, then f and e
-template <typename T, int V>
-__device__ __forceinline__ void pack_to_e(const float (&u)[3][V], const LinearTable* table, const MatrixLane& fwd, float (&e)[V][3]) {
-    float lin[V][3], xyz[V][3];
-#pragma unroll
-    for (int i = 0; i < V; ++i)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if constexpr (sizeof(T) == 1) lin[i][c] = table->lin[(int)u[c][i]]; else lin[i][c] = srgb_to_linear(u[c][i]);
-        }
+template <int V>
+__device__ __forceinline__ void lin_to_e(const float (&lin)[V][3], const MatrixLane& fwd, float (&e)[V][3]) {
+    float xyz[V][3];
     matrix_times_pack<V>(fwd, lin, xyz);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -147,6 +173,53 @@ __device__ __forceinline__ void pack_to_e(const float (&u)[3][V], const LinearTa
         xyz_to_f(xyz[i], f);
         f_to_e(f, e[i]);
     }
+}
+template <typename T, int V>
+__device__ __forceinline__ void pack_to_e(const float (&u)[3][V], const LinearTable* table, const MatrixLane& fwd, float (&e)[V][3]) {
+    float lin[V][3];
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (sizeof(T) == 1) lin[i][c] = table->lin[(int)u[c][i]]; else lin[i][c] = srgb_to_linear(u[c][i]);
+        }
+    lin_to_e<V>(lin, fwd, e);
+}
+// the statistics pass of a coded call: the pack's linear-light values from the code table where every element of the wave's packs is a
+// grey level, by the expression (and the tile marked) where not; the codes to the tile's planes
+template <int V>
+__device__ __forceinline__ void pack_to_e_coding(const float (&u)[3][V], const CodeLinTable& ct, const Codes& codes, int64_t tile, int64_t pixels, int64_t p, const MatrixLane& fwd, float (&e)[V][3]) {
+    static_assert(V == 4, "a pack of four codes is one 32-bit word of a plane");
+    float lin[V][3];
+    uint32_t word[3], differ = 0u;
+    const int copy = (int)(threadIdx.x % kCodeCopies);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        word[c] = 0u;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float x = u[c][i];
+            const uint32_t k = __float_as_uint(fmaf(x, 255.0f, 8388608.0f)) & 0xFFu;      // nearest grey level (anything else fails the comparison)
+            const uint2 entry = ct.e[k * kCodeCopies + copy];
+            differ |= entry.x ^ __float_as_uint(x);
+            lin[i][c] = __uint_as_float(entry.y);
+            word[c] |= k << (8 * i);
+        }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(differ != 0u) != 0ull, 0)) {
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float x = u[c][i];
+                asm volatile("" : "+v"(x));      // (a real branch, see macenko.hip code_pack())
+                lin[i][c] = srgb_to_linear(x);
+            }
+        if (differ != 0u) codes.bad[tile] = codes.epoch;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<uint32_t*>(codes.planes + ((size_t)tile * 3 + c) * pixels + p) = word[c];
+    lin_to_e<V>(lin, fwd, e);
 }
 // (uint8: the packs are loaded as grey levels, not unit values)
 template <typename T, int V>
@@ -186,13 +259,19 @@ struct Geometry {
 };
 
 template <typename T, int V>
-__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, State* __restrict__ st, double* __restrict__ partial, unsigned int* __restrict__ tile_arrivals, float* __restrict__ mean_out, float* __restrict__ std_out, double* __restrict__ sums_out, unsigned int call) {
+__global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restrict__ images, Geometry g, State* __restrict__ st, double* __restrict__ partial, unsigned int* __restrict__ tile_arrivals, float* __restrict__ mean_out, float* __restrict__ std_out, double* __restrict__ sums_out, unsigned int call, Codes codes = Codes{nullptr, nullptr, 0u}) {
     const int64_t tile = blockIdx.x / g.blocks_per_tile;
     const int chunk_id = blockIdx.x % g.blocks_per_tile;
     const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
     const T* img = images + tile * 3 * g.pixels;
     __shared__ LinearTable table;
     if constexpr (sizeof(T) == 1) table.fill();
+    constexpr bool kCodable = std::is_same<T, float>::value && V == 4;
+    __shared__ CodeLinTable code_table;
+    const bool coding = kCodable && codes.epoch != 0u;      // (uniform over the launch)
+    if constexpr (kCodable) {
+        if (coding) code_table.fill();
+    }
     const MatrixLane fwd = forward_matrix();
     double acc[kSums];
 #pragma unroll
@@ -204,7 +283,11 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
         for (int c = 0; c < 3; ++c) load_for_lab<T, V>(img + c * g.pixels + p, u[c]);
         float s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
         float e[V][3];
-        pack_to_e<T, V>(u, &table, fwd, e);
+        if constexpr (kCodable) {
+            if (coding) pack_to_e_coding<V>(u, code_table, codes, tile, g.pixels, p, fwd, e); else pack_to_e<T, V>(u, &table, fwd, e);
+        } else {
+            pack_to_e<T, V>(u, &table, fwd, e);
+        }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
 #pragma unroll
@@ -298,7 +381,7 @@ __global__ __launch_bounds__(kStreamThreads) void stats_kernel(const T* __restri
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restrict__ images, T* __restrict__ out, Geometry g, State* __restrict__ st, const float* __restrict__ ref_mean, const float* __restrict__ ref_std, unsigned int call) {
+__global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restrict__ images, T* __restrict__ out, Geometry g, State* __restrict__ st, const float* __restrict__ ref_mean, const float* __restrict__ ref_std, unsigned int call, Codes codes = Codes{nullptr, nullptr, 0u}) {
     const int64_t tile = blockIdx.x / g.blocks_per_tile;
     const int chunk_id = blockIdx.x % g.blocks_per_tile;
     const int64_t p_begin = (int64_t)chunk_id * g.chunk, p_end = min(p_begin + g.chunk, g.pixels);
@@ -318,13 +401,38 @@ __global__ __launch_bounds__(kStreamThreads) void apply_kernel(const T* __restri
     __shared__ LinearTable table;
     if constexpr (sizeof(T) == 1) table.fill();
     const MatrixLane fwd = forward_matrix(), inv = inverse_matrix();
+    // a tile of grey levels (see Codes): its codes in -- four bytes per lane and plane, the linear-light values from the table -- the same float pixels out
+    constexpr bool kCodable = std::is_same<T, float>::value && V == 4;
+    __shared__ UnitLinearTable unit_table;
+    bool coded = false;
+    if constexpr (kCodable) {
+        coded = codes.epoch != 0u && codes.bad[tile] != codes.epoch;      // (uniform over the workgroup)
+        if (coded) unit_table.fill();
+    }
+    const uint8_t* code_planes = kCodable && coded ? codes.planes + (size_t)tile * 3 * g.pixels : nullptr;
     for (int64_t p = p_begin + (int64_t)threadIdx.x * V; p < p_end; p += (int64_t)kStreamThreads * V) {
-        float u[3][V];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) load_for_lab_last<T, V>(img + c * g.pixels + p, u[c]);
         T res[3][V];
         float e[V][3], xyz[V][3], lin[V][3];
-        pack_to_e<T, V>(u, &table, fwd, e);
+        bool have_e = false;
+        if constexpr (kCodable) {
+            if (coded) {
+                uint32_t word[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) word[c] = *reinterpret_cast<const uint32_t*>(code_planes + (size_t)c * g.pixels + p);
+#pragma unroll
+                for (int i = 0; i < V; ++i)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) lin[i][c] = unit_table.lin[(word[c] >> (8 * i)) & 0xFFu];
+                lin_to_e<V>(lin, fwd, e);
+                have_e = true;
+            }
+        }
+        if (!have_e) {
+            float u[3][V];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) load_for_lab_last<T, V>(img + c * g.pixels + p, u[c]);
+            pack_to_e<T, V>(u, &table, fwd, e);
+        }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             // (fy = (L / 2.55 + 16) / 116, fx = (a - 128) / 500 + fy, fz = fy - (b - 128) / 200, :70-72: folded into k and cst)
@@ -397,9 +505,13 @@ __global__ void finalize_kernel(const double* __restrict__ sums, double n, State
 }
 
 static std::atomic<unsigned int> g_calls{0};      // numbers the calls (of every element type) for the ready-state check, see State
+static std::atomic<unsigned int> g_code_epoch{0x2545F491u};      // numbers the coded calls (see Codes): a flag word left by another call means nothing to this one
+// coded calls: float32 tiles of whole 4-pixel packs, batches of at least 2^20 pixels; the codes and the per-tile flags lie behind the workspace
+static bool coded_size(int64_t n, int64_t pixels) { return pixels % 4 == 0 && n * pixels >= (1ll << 20); }
+static size_t coded_bytes(int64_t n, int64_t pixels) { return align_up(sizeof(unsigned int) * (size_t)n, 256) + align_up((size_t)3 * pixels * n, 256); }
 
 template <typename T>
-static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, float* mean_out, float* std_out, double* sums_out, const double* sums_in, double n_total, void* ws, hipStream_t stream, bool ready) {
+static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, const float* ref_mean, const float* ref_std, float* mean_out, float* std_out, double* sums_out, const double* sums_in, double n_total, void* ws, size_t ws_bytes, hipStream_t stream, bool ready) {
     Geometry g{n, h * w, blocks_for(n, h * w), kStreamThreads * 4 * sweeps_for(n, h * w)};
     State* st = static_cast<State*>(ws);
     unsigned int* tile_arrivals = reinterpret_cast<unsigned int*>(static_cast<char*>(ws) + align_up(sizeof(State), 256));
@@ -408,6 +520,15 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, c
     const bool vec = (g.pixels % 4 == 0) && (reinterpret_cast<uintptr_t>(images) % (sizeof(T) * 4) == 0) && (!out || reinterpret_cast<uintptr_t>(out) % (sizeof(T) * 4) == 0);
     const unsigned grid = (unsigned)(n * g.blocks_per_tile);
     const T* in = static_cast<const T*>(images);
+    // float32 batches, statistics and apply pass in this one call: the tiles' 8-bit codes behind the workspace (see Codes)
+    Codes codes{nullptr, nullptr, 0u};
+    if (std::is_same<T, float>::value && vec && out && !sums_in && !sums_out && coded_size(n, g.pixels) && ws_bytes >= workspace_bytes(n, g.pixels) + coded_bytes(n, g.pixels)) {
+        char* base = static_cast<char*>(ws) + workspace_bytes(n, g.pixels);
+        codes.bad = reinterpret_cast<unsigned int*>(base);
+        codes.planes = reinterpret_cast<uint8_t*>(base + align_up(sizeof(unsigned int) * (size_t)n, 256));
+        codes.epoch = ++g_code_epoch;
+        if (codes.epoch == 0u) codes.epoch = ++g_code_epoch;
+    }
     unsigned int call = 0;
     if (sums_in) {            // statistics come from outside (all-reduced over ranks)
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, sums_in, n_total, st);
@@ -416,13 +537,13 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, c
         if (call == 0) call = ++g_calls;      // (0 means "no check" to the apply pass)
         if (!ready) hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, st, tile_arrivals, n);
         if (vec)
-            hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, tile_arrivals, mean_out, std_out, sums_out, call);
+            hipLaunchKernelGGL((stats_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, tile_arrivals, mean_out, std_out, sums_out, call, codes);
         else
             hipLaunchKernelGGL((stats_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, g, st, partial, tile_arrivals, mean_out, std_out, sums_out, call);
     }
     if (out) {
         if (vec)
-            hipLaunchKernelGGL((apply_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, static_cast<T*>(out), g, st, ref_mean, ref_std, ready ? call : 0u);
+            hipLaunchKernelGGL((apply_kernel<T, 4>), dim3(grid), dim3(kStreamThreads), 0, stream, in, static_cast<T*>(out), g, st, ref_mean, ref_std, ready ? call : 0u, codes);
         else
             hipLaunchKernelGGL((apply_kernel<T, 1>), dim3(grid), dim3(kStreamThreads), 0, stream, in, static_cast<T*>(out), g, st, ref_mean, ref_std, ready ? call : 0u);
     }
@@ -437,11 +558,11 @@ static int dispatch(const void* images, void* out, int dtype, int64_t n, int64_t
     if (reinterpret_cast<uintptr_t>(ws) % 256 != 0) return fail(SX_ERR_WORKSPACE, "workspace must be 256-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
-        case SX_U8: return run<uint8_t>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream, ready);
-        case SX_F16: return run<__half>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream, ready);
-        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream, ready);
-        case SX_F32: return run<float>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream, ready);
-        case SX_F64: return run<double>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, stream, ready);
+        case SX_U8: return run<uint8_t>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, ws_bytes, stream, ready);
+        case SX_F16: return run<__half>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, ws_bytes, stream, ready);
+        case SX_BF16: return run<__hip_bfloat16>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, ws_bytes, stream, ready);
+        case SX_F32: return run<float>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, ws_bytes, stream, ready);
+        case SX_F64: return run<double>(images, out, n, h, w, rm, rs, mo, so, sums_out, sums_in, n_total, ws, ws_bytes, stream, ready);
         default: return fail(SX_ERR_DTYPE, "unsupported dtype code %d", dtype);
     }
 }
@@ -454,6 +575,14 @@ using namespace sx;
 extern "C" size_t sx_reinhard_workspace_bytes(int64_t n, int64_t h, int64_t w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
     return reinhard::workspace_bytes(n, h * w);
+}
+// ... with room for the 8-bit codes of a float32 batch (3 bytes per pixel): sx_reinhard_transform(_ready) then reads the tiles that consist
+// of grey levels as bytes in its second pass.  A call on the smaller workspace of sx_reinhard_workspace_bytes() runs without.
+extern "C" size_t sx_reinhard_workspace_bytes_for(int dtype, int64_t n, int64_t h, int64_t w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    size_t need = reinhard::workspace_bytes(n, h * w);
+    if (dtype == SX_F32 && reinhard::coded_size(n, h * w)) need += reinhard::coded_bytes(n, h * w);
+    return need;
 }
 
 extern "C" int sx_reinhard_fit(const void* images, int dtype, int64_t n, int64_t h, int64_t w, float* mean_out, float* std_out, void* ws, size_t ws_bytes, void* stream) {

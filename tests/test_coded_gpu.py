@@ -136,3 +136,55 @@ def test_product_library_takes_the_codes_and_matches_the_oracle(dev):
     got = be.transform(x.to(dev), sm, tmc, _extra_flags=CLASSIC).cpu().numpy()
     want = so.macenko_transform(x.numpy(), sm.numpy(), tmc.numpy())
     assert np.abs(got - want).max() <= 2.55e-2      # 0-255 scale (the tolerance of tests/test_macenko_gpu.py)
+
+
+# ---- Reinhard: the same codes between its statistics pass and its apply pass (stainx_amd/csrc/reinhard.hip: Codes) ---------------------
+def _reinhard_both(dev, x, mean, std):
+    """(with the codes, without): the C ABI on a workspace with / without room for them."""
+    lib = _native.require()
+    n, _, h, w = x.shape
+    code = _native.DTYPE_CODES[x.dtype]
+    outs = []
+    for nbytes in (int(lib.sx_reinhard_workspace_bytes_for(code, n, h, w)), int(lib.sx_reinhard_workspace_bytes(n, h, w))):
+        ws = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=dev)
+        out = torch.empty_like(x)
+        rc = lib.sx_reinhard_transform(x.data_ptr(), out.data_ptr(), code, n, h, w, mean.data_ptr(), std.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr(dev))
+        _native.check(rc, "sx_reinhard_transform")
+        torch.cuda.synchronize()
+        outs.append(out)
+    return outs
+
+
+@pytest.mark.parametrize("shape", [(16, 256, 256), (8, 512, 512), (24, 224, 224), (9, 300, 500), (5, 300, 500)])
+def test_reinhard_coded_equals_plain(dev, shape):
+    n, h, w = shape
+    lib = _native.require()
+    f32 = _native.DTYPE_CODES[torch.float32]
+    if n * h * w >= 1 << 20:      # (smaller batches run without: their passes are bound by latency, not by bytes)
+        assert lib.sx_reinhard_workspace_bytes_for(f32, n, h, w) >= lib.sx_reinhard_workspace_bytes(n, h, w) + 3 * n * h * w
+    assert lib.sx_reinhard_workspace_bytes_for(_native.DTYPE_CODES[torch.uint8], n, h, w) == lib.sx_reinhard_workspace_bytes(n, h, w)
+    mean = torch.tensor([170.0, 150.0, 120.0], dtype=torch.float32, device=dev)
+    std = torch.tensor([40.0, 12.0, 9.0], dtype=torch.float32, device=dev)
+    x = synth.as_dtype(synth.he_batch(n, h, w, seed0=4700 + n), torch.float32).to(dev)
+    coded, plain = _reinhard_both(dev, x, mean, std)
+    assert torch.equal(coded, plain)
+    # tiles that are not grey levels, and a batch that mixes the two kinds
+    y = x.clone()
+    y[1] = (y[1] + 3e-4).clamp(0.0, 1.0)
+    y[n - 1, 2, h - 1, w - 1] = float("nan") if n > 5 else 0.777
+    coded, plain = _reinhard_both(dev, y, mean, std)
+    assert torch.equal(torch.nan_to_num(coded, nan=-1.0), torch.nan_to_num(plain, nan=-1.0))
+
+
+def test_reinhard_backend_takes_the_codes_and_matches_the_oracle(dev):
+    from oracle import stain_oracle as so
+    from stainx_amd.backends.torch_hip_backend import ReinhardHIP
+
+    be = ReinhardHIP(dev)
+    x = synth.as_dtype(synth.he_batch(16, 256, 256, seed0=4800), torch.float32)
+    mean, std = so.reinhard_fit(synth.reference_tile(96, 96).numpy())
+    want = so.reinhard_transform(x.numpy(), mean, std)
+    for _ in range(2):      # (the second call runs on the READY workspace)
+        got = be.transform(x.to(dev), torch.from_numpy(mean), torch.from_numpy(std)).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-4
+    assert be.workspace_status() == 0
