@@ -264,6 +264,14 @@ int sx_hm_transform(const void* images_dev, void* out_dev, int dtype, int64_t n_
  * (torch_backend.py:139, histogram_matching.cu:49-81). */
 int sx_hm_workspace_init(void* workspace_dev, size_t workspace_bytes, void* stream);
 size_t sx_hm_workspace_status_offset(void);
+#ifdef SX_DIAG
+/* Diagnostic build: planar uint8 batches of at least 32 MB take the transform entry points above in ONE launch (workgroups keep part of the batch in
+ * registers between counting and applying: same bits, measured slower than the two kernels -- DESIGN.md section 5; SX_HM_RESIDENT=0 in the
+ * environment switches it off).  The uint32 at byte sx_hm_workspace_parity_offset() of the workspace toggles with every call that took
+ * that form; sx_debug_hm_stamp_offset(): its phase stamps. */
+size_t sx_hm_workspace_parity_offset(void);
+size_t sx_debug_hm_stamp_offset(void);
+#endif
 int sx_hm_fit_ready(const void* images_dev, int dtype, int64_t n_tiles, int64_t height, int64_t width,
                     int channels_last, float* hist_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 int sx_hm_transform_ready(const void* images_dev, void* out_dev, int dtype, int64_t n_tiles, int64_t height,

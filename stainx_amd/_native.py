@@ -96,11 +96,22 @@ _load_error: str | None = None
 _diag_lib = None
 
 
+# entry points only the diagnostic build exports (include/stainx_hip.h, #ifdef SX_DIAG)
+DIAG_SIGNATURES = {
+    "sx_hm_workspace_parity_offset": (_sz, []),
+    "sx_debug_hm_stamp_offset": (_sz, []),
+}
+
+
 def _open(path: Path):
     lib = ctypes.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    for name, (res, args) in DIAG_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = res, args
     got = lib.sx_version()
     if got != ABI_VERSION:
         raise OSError(f"ABI version {got} != expected {ABI_VERSION}")

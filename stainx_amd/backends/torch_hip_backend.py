@@ -531,8 +531,10 @@ class ReinhardHIP(TorchHIPBackendBase):
 class HistogramMatchingHIP(TorchHIPBackendBase):
     """Histogram matching on the GPU (numerics of HistogramMatchingTorch, torch_backend.py:134-301)."""
 
-    def __init__(self, device: str | torch.device | None = None, channel_axis: int = 1):
+    def __init__(self, device: str | torch.device | None = None, channel_axis: int = 1, diag: bool = False):
         super().__init__(device)
+        if diag:      # tests / tools: the diagnostic build (the one-launch design study lives there)
+            self._lib = _native.require_diag()
         self.channel_axis = channel_axis
         self.last_workspace: torch.Tensor | None = None
         # the workspace is zero-filled when it is made and every library call leaves it zeroed again: the sx_hm_*_ready entry

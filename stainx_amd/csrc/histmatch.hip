@@ -16,12 +16,17 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
+#include <cstdlib>
+#include <type_traits>
 
 namespace sx {
 namespace histmatch {
 
 constexpr int kBins = 256;
+constexpr int kResSets = 16;            // one-launch form: sets of pooled counters per parity
+constexpr int kResMaxChunks = 8192;     // ... and the most chunks (176 KB each) a batch may have to take it (1.4 GB)
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / kWave;
 
@@ -35,6 +40,16 @@ struct alignas(256) Tables {
     // hipMemsetAsync launch in front of the histogram pass (5 us of a 115 us call); the plain entry points clear them first.
     uint32_t counts[3][kBins];
     uint32_t status;                // bit 0: a *_ready call found counters that do not add up to the pixels it counted (workspace not ready)
+#ifdef SX_DIAG
+    // the one-launch form (histmatch_resident.hpp, diagnostic build): sets of pooled counters in two parities used alternately -- a call adds
+    // into parity `res_parity` and clears the other -- and its chunk flags
+    uint32_t res_counts[2][kResSets][3][kBins];
+    uint32_t res_parity;
+    uint32_t res_done, res_leave;         // chunks counted; workgroups that have left
+    uint32_t res_flag[kResMaxChunks];     // chunk claimed for counting
+    uint32_t res_flag2[kResMaxChunks];    // chunk claimed for the apply phase (or kept in somebody's registers)
+    unsigned long long res_stamp[8];      // wall_clock64() of workgroup 0 at the phase boundaries of the one-launch form
+#endif
 };
 
 struct Layout {
@@ -189,8 +204,7 @@ __global__ void widen_kernel(Tables* __restrict__ tab, unsigned long long* __res
 
 // One LUT entry: where the source's running sum s of grey level t falls among the reference's running sums.  InT decides the range
 // rules of the output (:288-298).
-template <typename T>
-__device__ __forceinline__ void lut_entry(Tables* __restrict__ tab, int c, int t, float s, const float* ref_cdf) {
+__device__ __forceinline__ float lut_value(float s, const float* ref_cdf) {
     // searchsorted(right=False): first index with ref_cdf[idx] >= s; clamp to [1,255] (:260-261)
     int lo = 0, hi = kBins;
     while (lo < hi) {
@@ -204,7 +218,11 @@ __device__ __forceinline__ void lut_entry(Tables* __restrict__ tab, int c, int t
     float v = (float)(idx - 1) + alpha * ((float)idx - (float)(idx - 1));             // :276
     if (s <= ref_cdf[0]) v = 0.0f;                                                    // :268, :279
     if (s >= ref_cdf[kBins - 1]) v = 255.0f;                                          // :269, :280
-    v = fminf(fmaxf(v, 0.0f), 255.0f);                                                // :281
+    return fminf(fmaxf(v, 0.0f), 255.0f);                                             // :281
+}
+template <typename T>
+__device__ __forceinline__ void lut_entry(Tables* __restrict__ tab, int c, int t, float s, const float* ref_cdf) {
+    const float v = lut_value(s, ref_cdf);
     tab->lut[c][t] = v;
     if constexpr (sizeof(T) == 1) {
         tab->typed_lut[c][t] = pack_elem<uint8_t>((uint8_t)v);                        // stays 0..255, truncated
@@ -361,7 +379,45 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const T* __restrict__ i
     }
 }
 
+#ifdef SX_DIAG
+}  // namespace histmatch
+}  // namespace sx
+#include "histmatch_resident.hpp"
+namespace sx {
+namespace histmatch {
+#endif
+
 static size_t workspace_bytes() { return sizeof(Tables); }
+
+#ifdef SX_DIAG
+// The one-launch form (histmatch_resident.hpp): planar uint8 batches of at least 32 MB whose planes are whole sweeps.  One workgroup per CU
+// (an ordinary launch: the kernel does not depend on its workgroups being resident together).
+static int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+        cached[dev] = n;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
+static bool resident_shape(int64_t n, int64_t pixels) {
+    const int64_t sweeps = pixels % kResSweepBytes == 0 ? n * 3 * (pixels / kResSweepBytes) : 0;
+    return sweeps >= 2048 && (sweeps + kResChunkSweeps - 1) / kResChunkSweeps <= kResMaxChunks;      // (at least 32 MB: smaller batches are bound by latency either way)
+}
+static bool run_resident(const uint8_t* images, uint8_t* out, int64_t n, int64_t pixels, Tables* tab, const float* ref_hist, hipStream_t stream) {
+    const int cus = device_cus();
+    if (cus <= 0) return false;
+    const int64_t total_sweeps = n * 3 * (pixels / kResSweepBytes);
+    const int sweeps_per_plane = (int)(pixels / kResSweepBytes);
+    const int64_t chunks = (total_sweeps + kResChunkSweeps - 1) / kResChunkSweeps;
+    const unsigned grid = (unsigned)std::min<int64_t>(cus, chunks);
+    hipLaunchKernelGGL(resident_kernel, dim3(grid), dim3(kResThreads), 0, stream, images, out, total_sweeps, sweeps_per_plane, tab, ref_hist, (double)(n * pixels));
+    return true;
+}
+#endif
 
 template <typename T>
 static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, int channels_last, const float* ref_hist, float* hist_out, unsigned long long* counts_out, const unsigned long long* counts_in, double n_total, void* ws, hipStream_t stream, bool ready) {
@@ -377,7 +433,15 @@ static int run(const void* images, void* out, int64_t n, int64_t h, int64_t w, i
     const unsigned grid = (unsigned)std::min<int64_t>((total + per_block - 1) / per_block, 256 * 8);
     double lut_pixels = n_total;
     if (!counts_in) {
-        if (!ready && hipMemsetAsync(tab->counts, 0, sizeof(tab->counts) + sizeof(tab->status), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
+        if (!ready && hipMemsetAsync(tab->counts, 0, sizeof(Tables) - offsetof(Tables, counts), stream) != hipSuccess) return fail(SX_ERR_LAUNCH, "hipMemsetAsync failed");
+#ifdef SX_DIAG
+        if constexpr (std::is_same<T, uint8_t>::value) {
+            static const int mode = [] { const char* e = std::getenv("SX_HM_RESIDENT"); return e ? std::atoi(e) : 1; }();
+            if (mode != 0 && vec && !channels_last && out && !hist_out && !counts_out && resident_shape(n, lay.pixels)) {
+                if (run_resident(in, static_cast<uint8_t*>(out), n, lay.pixels, tab, ref_hist, stream)) return check_launch("histogram transform (one launch)");
+            }
+        }
+#endif
         if (vec && !channels_last) {
             const int chunks_per_plane = (int)((lay.pixels + kPlaneChunk - 1) / kPlaneChunk);
             hipLaunchKernelGGL((histogram_planar_kernel<T>), dim3((unsigned)(n * 3 * chunks_per_plane)), dim3(kPlaneThreads), 0, stream, in, lay, chunks_per_plane, &tab->counts[0][0]);
@@ -451,6 +515,11 @@ extern "C" int sx_hm_workspace_init(void* ws, size_t ws_bytes, void* stream) {
 }
 
 extern "C" size_t sx_hm_workspace_status_offset(void) { return offsetof(histmatch::Tables, status); }
+#ifdef SX_DIAG
+// (tests and tools: the word every call in the one-launch form toggles; its phase stamps)
+extern "C" size_t sx_hm_workspace_parity_offset(void) { return offsetof(histmatch::Tables, res_parity); }
+extern "C" size_t sx_debug_hm_stamp_offset(void) { return offsetof(histmatch::Tables, res_stamp); }
+#endif
 
 extern "C" int sx_hm_fit_ready(const void* images, int dtype, int64_t n, int64_t h, int64_t w, int channels_last, float* hist_out, void* ws, size_t ws_bytes, void* stream) {
     if (!hist_out) return fail(SX_ERR_BAD_ARG, "hist_out pointer is null");

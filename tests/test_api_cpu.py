@@ -21,12 +21,21 @@ ROOT = Path(__file__).resolve().parents[1]
 
 def test_library_exports_every_declared_symbol():
     header = (ROOT / "include" / "stainx_hip.h").read_text()
-    declared = set(re.findall(r"\b(sx_[a-z0-9_]+)\s*\(", header))
+    # (what stands between `#ifdef SX_DIAG` and its `#endif` is the diagnostic build's: exported by libstainx_diag.so only)
+    diag_part = "".join(re.findall(r"#ifdef SX_DIAG(.*?)#endif", header, flags=re.S))
+    diag_only = set(re.findall(r"\b(sx_[a-z0-9_]+)\s*\(", diag_part))
+    declared = set(re.findall(r"\b(sx_[a-z0-9_]+)\s*\(", header)) - diag_only
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    assert diag_only == set(_native.DIAG_SIGNATURES), diag_only ^ set(_native.DIAG_SIGNATURES)
     assert _native.library_available(), _native._load_error
     lib = ctypes.CDLL(str(_native.LIB_PATH))
     for name in declared:
         assert hasattr(lib, name), name
+    for name in diag_only:
+        assert not hasattr(lib, name), name
+    diag = ctypes.CDLL(str(_native.DIAG_LIB_PATH))
+    for name in declared | diag_only:
+        assert hasattr(diag, name), name
     assert _native.require().sx_version() == _native.ABI_VERSION
     # size queries are pure host functions
     assert _native.require().sx_macenko_workspace_bytes(64, 512, 512) > 0
