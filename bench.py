@@ -2,7 +2,7 @@
 """Headline benchmark: megapixels/s of ``Macenko.transform`` on 64x3x512x512 fp32 tiles per GPU
 (BASELINE.json configs[1]), inputs resident in HBM, reference-mode (fit once, excluded from timing).
 
-    python bench.py --gpus N --steps K --warmup W [--workload transform|fit_transform_pooled|hm_config3|module_config5|real_tiles]
+    python bench.py --gpus N --steps K --warmup W [--workload transform|fit_transform_pooled|hm_config3|module_config5|real_tiles|reinhard_f32]
 
 For N > 1 the job is one rank per GPU over RCCL: either the driver launches this file under ``torch.distributed.run`` (WORLD_SIZE /
 RANK / LOCAL_RANK in the environment), or -- ``python bench.py --gpus N`` as it stands -- this process starts the N ranks ITSELF
@@ -65,7 +65,7 @@ def parse() -> argparse.Namespace:
     # multiplies ms_per_step several times, inside 1000 steps it adds half.
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", choices=("transform", "fit_transform_pooled", "hm_config3", "module_config5", "real_tiles"), default="transform")
+    ap.add_argument("--workload", choices=("transform", "fit_transform_pooled", "hm_config3", "module_config5", "real_tiles", "reinhard_f32"), default="transform")
     ap.add_argument("--batches", type=int, default=2, help="different input batches the timed loop rotates over (1: one buffer)")
     ap.add_argument("--cpu-tiles", type=int, default=64, help="tiles of the workload the CPU baseline is timed on")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -108,7 +108,8 @@ def _cpu_worker_any(args):
 
     from oracle import stain_oracle as so
 
-    fn = (lambda x: so.hm_transform(x, so.hm_fit(params[0]))) if kind == "hm" else (lambda x: so.macenko_transform(x, params[0], params[1]))
+    fn = ((lambda x: so.hm_transform(x, so.hm_fit(params[0]))) if kind == "hm" else (lambda x: so.reinhard_transform(x, params[0], params[1])) if kind == "reinhard"
+          else (lambda x: so.macenko_transform(x, params[0], params[1])))
     with threadpool_limits(limits=1):
         fn(sample[:1])
         reps, t0 = 0, time.perf_counter()
@@ -194,7 +195,7 @@ def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
     import numpy as np
 
     from oracle import stain_oracle as so
-    from stainx_amd import HistogramMatching, Macenko, StainNormalizerTransform, synth
+    from stainx_amd import HistogramMatching, Macenko, Reinhard, StainNormalizerTransform, synth
 
     n_batches = max(1, args.batches)
     if args.workload == "hm_config3":
@@ -222,6 +223,19 @@ def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
         cpu_fn = lambda sample: so.macenko_transform(sample, he, max_c)
         cpu_sample, exact = batches_cpu[0][:32].float().numpy(), False
         cpu_kind, cpu_params, cpu_many = "macenko", (he, max_c), batches_cpu[0][:256].float().numpy()
+    elif args.workload == "reinhard_f32":
+        n, h, w, bpp, dt_name = 64, 512, 512, 24, "f32"
+        ref = synth.as_dtype(synth.reference_tile(h, w), torch.float32)
+        batches_cpu = [synth.as_dtype(synth.he_batch(n, h, w, seed0=1000 + n * (rank + world * b)), torch.float32) for b in range(n_batches)]
+        norm = Reinhard(device=dev, backend="torch_hip").fit(ref.to(dev))
+        call = norm.transform
+        metric = "megapixels/sec Reinhard transform, 64x3x512x512 fp32"
+        workload = "Reinhard transform (LAB statistics pooled over the batch), 64x3x512x512 fp32 per GPU (the sibling of BASELINE configs[1])"
+        kernel = "statistics pass (leaves the tiles' 8-bit codes) + apply pass (reads them): 12 R + 3 W + 3 R + 12 W bytes per pixel moved for the 24 algorithmic"
+        r_mean, r_std = so.reinhard_fit(ref.numpy())
+        cpu_fn = lambda sample: so.reinhard_transform(sample, r_mean, r_std)
+        cpu_sample, exact = batches_cpu[0][:16].numpy(), False
+        cpu_kind, cpu_params, cpu_many = "reinhard", (r_mean, r_std), batches_cpu[0][:16].numpy()
     else:
         n, h, w, bpp, dt_name = 64, 512, 512, 24, "f32"
         imgs = torch.from_numpy(np.load(str(ROOT / "tests" / "golden" / "g11_real_images.npz"))["images_u8"])
@@ -265,7 +279,7 @@ def other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
         got = call(batches[0][:k].contiguous()).float().cpu()
         w_t = torch.from_numpy(np.asarray(want)).float() / (255.0 if args.workload == "module_config5" else 1.0)
         line["max_abs_vs_oracle"] = float((got - w_t).abs().max())
-        line["max_abs_vs_oracle_note"] = "grey levels, bit-exact expected" if exact else ("[0, 1] scale (module default normalize_to_0_1), bf16 storage" if args.workload == "module_config5" else "0-255 scale")
+        line["max_abs_vs_oracle_note"] = "grey levels, bit-exact expected" if exact else ("[0, 1] scale (module default normalize_to_0_1), bf16 storage" if args.workload == "module_config5" else "[0, 1] scale (float tiles in, float tiles out)" if args.workload == "reinhard_f32" else "0-255 scale")
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(line), flush=True)
@@ -385,7 +399,7 @@ def main() -> None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    if args.workload in ("hm_config3", "module_config5", "real_tiles"):
+    if args.workload in ("hm_config3", "module_config5", "real_tiles", "reinhard_f32"):
         other_workload(args, dev, rank, world, barrier, max_over_ranks, real_stdout)
         if distributed:
             dist.barrier()
