@@ -251,6 +251,10 @@ __device__ __forceinline__ void running_sum(const float* term, float* cdf) {
 }
 
 // One workgroup of 256 threads per channel.
+// (Round 4 tried the tables inside the APPLY launch -- every workgroup builds them from the final counters in its prologue, the workgroup
+// that reads the counters last consumes them: same bits, 0.118 -> 0.142 ms per call.  Each workgroup runs six sequential chains of 256
+// double-precision additions (torch.cumsum's order), and with eight workgroups per CU the chains of a CU share its four SIMDs: a 25 us
+// prologue; with 1024-thread workgroups, two per CU, 0.124 ms -- still behind this 8.4 us launch of three workgroups.)
 // (Tried: the LUT inside the histogram launch -- its first workgroup prepares the reference's running sums, the workgroup whose counts
 // arrive last does the rest -- to save this launch and its boundary.  Same bits, and slower: 121 against 114 us per call.  Every one of
 // the 3072 workgroups then waits for its counter adds to be acknowledged and for a ticket from ONE address before it may leave its
@@ -362,7 +366,10 @@ __global__ __launch_bounds__(kThreads) void apply_kernel(const T* __restrict__ i
     const int64_t total = lay.elements();
     constexpr int V = kVec ? VecOf<T>::n : 1;
     const int64_t stride = (int64_t)gridDim.x * kThreads * V;
-    for (int64_t e = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * V; e < total; e += stride) {
+    for (int64_t e0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * V; e0 < total; e0 += stride) {
+        // Back to front: the histogram pass read the batch front to back, so this pass starts on what the Infinity Cache got last (config 3,
+        // rotating two batches, A/B on one box: 0.1213 / 0.1201 -> 0.1188 / 0.1179 ms per call).
+        const int64_t e = total - V - e0;
         if constexpr (kVec) {
             const Pack<T, V> pk = *reinterpret_cast<const Pack<T, V>*>(images + e);      // (non-temporal loads here: no gain over rotating batches, 3 us lost on one buffer -- tools/ab_rotating_siblings.py)
             Pack<T, V> res;
