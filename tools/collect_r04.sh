@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04; mkdir -p $O
 bash $R/tools/collect_profiles.sh r04 $HEAD > $O/collect_profiles.log 2>&1; echo "headline done"
 cd /tmp && export TMPDIR=/tmp
-for wl in hm_config3 module_config5 real_tiles; do
+for wl in hm_config3 module_config5 real_tiles reinhard_f32; do
   timeout -k 10 300 python3 $R/bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err; echo "bench $wl done"
 done
 bash $R/tools/collect_siblings.sh r04/sib > $O/collect_siblings.log 2>&1; echo "sibling traces done"
