@@ -166,6 +166,7 @@ struct Workspace {
     struct FusedSched* fsched;    // fused transform: the launch's ticket counter and error word
     struct FusedTile* ftile;      // fused transform: per tile, the counters the roles of the launch hand each other work through
     uint4* cand_rec;              // fused transform: [n_tiles][kSlots][fused_cap] candidate records (od0, od1, od2, -)
+    uint32_t* dense_spill;        // two-pass transform, dense records: [n_tiles][kSlots][fused_cap - kLdsKeys] keys of a slot beyond the stages' LDS array
     uint32_t* code_bad;           // coded four passes: [n_tiles] the number of the last call whose first pass found a non-8-bit element in the tile
     uint8_t* codes;               // coded four passes: [n_tiles][3][pixels] grey-level codes (both overlay the areas behind the base level: the four passes use none of them)
 };
@@ -218,6 +219,17 @@ static bool two_pass_size(int64_t pixels) { return pixels >= 256 && pixels <= 64
 constexpr uint32_t kFusedCapMax = 14336;      // (256 threads x 32 keys in registers + 6144 keys in LDS: macenko_fused.hpp)
 static bool fused_size(int64_t pixels) { return pixels >= 16384 && pixels <= 262144 && pixels % 4 == 0; }
 static uint32_t fused_cap_for(int64_t pixels) { return (uint32_t)std::min<int64_t>(kFusedCapMax, std::max<int64_t>(2048, (pixels / 4 + 255) / 256 * 256)); }
+// The four-launch two-pass form's dense records (round 4): an eighth of the tile's pixels per slot, at most 24576 -- the stage keeps the
+// first kLdsKeys keys of a slot in LDS and spills the rest (dense_spill).  With the fused launch's 14336 (5.5 % of a 512 x 512 tile) the
+// reference's real tiles overflowed: their second concentration slot holds up to 6.5 % of the pixels, an angle slot 3 % on average and
+// 10.5 % at most, and an overflow sends the slot to the whole-tile select -- eight of the ten slow slots of tools/diag_real.py's twenty
+// tiles.  Over the 150 crops of tools/diag_real_batches.py: 14336 -> (many), 20480 -> 23 tiles with a slow slot (9 of them an overflowing
+// angle slot), 32768 -> 15 (none overflowing); 24576 (9.4 % of a 512 x 512 tile) holds all but the one 10.5 % slot and is 34 MB less
+// workspace for config 2 than 32768.
+constexpr uint32_t kDenseCapMax = 24576;
+static uint32_t dense_cap_for(int64_t pixels) { return (uint32_t)std::min<int64_t>(kDenseCapMax, std::max<int64_t>(2048, (pixels / 8 + 255) / 256 * 256)); }
+static uint32_t record_cap_for(int64_t pixels) { return std::max(fused_cap_for(pixels), dense_cap_for(pixels)); }      // what the record area is sized for
+static size_t dense_spill_words(int64_t pixels) { return dense_cap_for(pixels) > (uint32_t)kLdsKeys ? (size_t)dense_cap_for(pixels) - kLdsKeys : 0; }
 constexpr size_t kFusedSchedBytes = 512, kFusedTileBytes = 64;
 
 // The workspace is laid out so that what a form of the transform needs is a PREFIX of the whole:
@@ -241,7 +253,8 @@ static size_t workspace_bytes(int64_t n_tiles, int64_t pixels, int level = kWsTw
         total += align_up(kPriorRecordBytes * n, 256);
         total += kFusedSchedBytes;
         total += align_up(kFusedTileBytes * n, 256);
-        if (fused_size(pixels)) total += align_up(sizeof(uint4) * kSlots * (size_t)fused_cap_for(pixels) * n, 256);
+        if (fused_size(pixels)) total += align_up(sizeof(uint4) * kSlots * (size_t)record_cap_for(pixels) * n, 256);
+        if (fused_size(pixels)) total += align_up(sizeof(uint32_t) * kSlots * dense_spill_words(pixels) * n, 256);
     }
     if (level >= kWsTwoPass && two_pass_size(pixels)) {
         total += align_up(sizeof(float) * 3 * kSlots * (size_t)cap2_for(pixels) * n, 256);
@@ -283,7 +296,9 @@ static Workspace carve(void* base, int64_t n_tiles, int64_t pixels, size_t codes
     w.ftile = reinterpret_cast<FusedTile*>(p);
     p += align_up(kFusedTileBytes * n, 256);
     w.cand_rec = reinterpret_cast<uint4*>(p);
-    if (fused_size(pixels)) p += align_up(sizeof(uint4) * kSlots * (size_t)fused_cap_for(pixels) * n, 256);
+    if (fused_size(pixels)) p += align_up(sizeof(uint4) * kSlots * (size_t)record_cap_for(pixels) * n, 256);
+    w.dense_spill = reinterpret_cast<uint32_t*>(p);
+    if (fused_size(pixels)) p += align_up(sizeof(uint32_t) * kSlots * dense_spill_words(pixels) * n, 256);
     w.cand_od = reinterpret_cast<float*>(p);
     p += align_up(sizeof(float) * 3 * kSlots * (size_t)cap2_for(pixels) * n, 256);
     w.seg_count = reinterpret_cast<uint32_t*>(p);
@@ -3066,7 +3081,7 @@ static int transform_typed(const void* images, void* out, const Geometry& g0, co
         knob("SX_SPEC_SIGMAS_CONC", g.spec_sigmas_conc);
         knob("SX_SPEC_TSCALE", g.spec_tscale);
 #endif
-        g.fused_cap = fused_cap_for(g.pixels);
+        g.fused_cap = g.fused ? fused_cap_for(g.pixels) : dense_cap_for(g.pixels);      // (records per tile and slot: the fused launch's, or the four launches' dense arrays)
         g.fused_items = (int)(g.n_tiles * g.blocks_per_tile);
         g.cap2 = cap2_for(g.pixels);
         g.n_seg = even_items_size(g.pixels) ? g.blocks_per_tile * (kStreamThreads / kWave) : two_pass_segments(g.pixels);      // (dense records there: no segments; the count of pass-A waves per tile all the same)

@@ -44,6 +44,11 @@ constexpr int kPriorSweeps = 4;                       // 4-pixel quads a thread 
 constexpr int kPriorUnitsMax = kGroupThreads / 4 * kPriorSweeps;      // sectors of 16 pixels per tile: 1024
 constexpr int kQueue2 = 512;                          // 16-byte records a wave queues in LDS before it must flush
 constexpr float kSpecSigmasConc = 5.0f, kSpecThresholdScale = 1.0f;      // the concentration thresholds: their quantile's distance below 99 % in standard deviations, and a factor on them
+// (Round 4, tools/diag_real_batches.py over 150 real crops, after the dense records' capacity went from 14336 to 32768: at 5, 15 tiles have a
+// slow slot -- 11 of them a concentration answer below its bound --, at 8 only the 4 whose frame check fails in all four slots (a plane
+// estimated from a sample is not the tile's plane there: not a matter of margins).  8 costs the synthetic headline 0.148 -> 0.153 ms (0.7 +
+// 1.3 % more candidates in the two slots) and changes nothing for a 64-tile batch of real tissue, which has such a tile 8 times in 10 and
+// runs the four passes either way: 5 stays.)
 constexpr float kSpecSigmas = 5.0f;                   // half-width of a bracket in standard deviations of the sample quantile
 // Independent samples per 16-pixel sector (four of its pixels enter the histograms: neighbours).  Sectors far apart -- at least
 // 8 sector lengths between sampled ones: tiles from ~360x360 -- are taken for TWO (sweeps over 3840 tiles of 512x512 / 256x256 and
@@ -1322,7 +1327,9 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     const bool stamps = j == 0;
     if (stamps) SX_STAMP(st, 8);
     const float* c0 = ws.cand_od + ((size_t)tile * kSlots + j) * 3 * g.cap2;
-    const size_t spill_words = (!kDense && g.cap2 > (uint32_t)kLdsKeys) ? g.cap2 - kLdsKeys : 0u;      // (a dense array holds at most kLdsKeys records: no spill)
+    // (keys of a slot beyond the LDS array: the per-wave segments' total, or the dense array's capacity)
+    const size_t spill_words = kDense ? (g.fused_cap > (uint32_t)kLdsKeys ? g.fused_cap - kLdsKeys : 0u) : (g.cap2 > (uint32_t)kLdsKeys ? g.cap2 - kLdsKeys : 0u);
+    uint32_t* const spill_area = kDense ? ws.dense_spill : ws.key_spill;
     // (tile and slot are workgroup-uniform; said so, the descriptors stay in scalar registers)
     const uint4* rec_tile = ws.cand_rec + (size_t)__builtin_amdgcn_readfirstlane(tile) * kSlots * g.fused_cap;
     const auto rsrc_phi = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(rec_tile + (size_t)__builtin_amdgcn_readfirstlane(j) * g.fused_cap), 0, (int)(g.fused_cap * 16u), 0x00020000);
@@ -1345,7 +1352,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
         const unsigned long long rank = nearest_rank_index(j ? 99.0 : 1.0, n_sel);      // alpha = 1 (torch_backend.py:421-422)
         rank_other = nearest_rank_index(j ? 1.0 : 99.0, n_sel);
         bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !use_all && !g.spec_fail && sh.seg_overflow == 0 && rank >= below && rank - below < n;
-        uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + j) * spill_words;
+        uint32_t* spill = spill_area + ((size_t)tile * kSlots + j) * spill_words;
         uint32_t answer = 0, why = 1u;
         if (ok) {      // uniform
             // the exact keys of the candidates and their range; one thread works out the proof obligations meanwhile
@@ -1454,7 +1461,7 @@ __global__ __launch_bounds__(kGroupThreads) void estimate_stage_kernel(const T* 
     bool ok = mode == 0 && (spec & (kSpecSlow | kSpecHazard)) == 0 && !g.spec_fail && sh.seg_overflow == 0 && k99 >= outside && n > 0;
     uint32_t why = ok && sh.ok == 0 ? 2u : 1u;
     ok = ok && sh.ok != 0;
-    uint32_t* spill = ws.key_spill + ((size_t)tile * kSlots + slot) * spill_words;
+    uint32_t* spill = spill_area + ((size_t)tile * kSlots + slot) * spill_words;
     uint32_t answer = 0;
     if (ok) {
         const uint32_t k_floor = sh.k_floor, k_ceil = sh.k_ceil;

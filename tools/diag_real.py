@@ -8,7 +8,7 @@ from tests.golden.cases import real_quadrants_512
 dev = torch.device("cuda:0")
 root = __import__("pathlib").Path(__file__).resolve().parents[1]
 imgs = torch.from_numpy(np.load(str(root / "tests/golden/g11_real_images.npz"))["images_u8"])
-be = MacenkoHIP(dev)
+be = MacenkoHIP(dev, diag=True)
 sm, tmc = be.compute_reference_stain_matrix(imgs[0:1].to(dev))
 quads = torch.stack([imgs[i, :, y:y + 512, x:x + 512] for i, y, x in real_quadrants_512()]).contiguous()
 x = synth.as_dtype(quads, torch.float32).to(dev)
