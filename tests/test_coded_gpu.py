@@ -188,3 +188,32 @@ def test_reinhard_backend_takes_the_codes_and_matches_the_oracle(dev):
         got = be.transform(x.to(dev), torch.from_numpy(mean), torch.from_numpy(std)).cpu().numpy()
         assert np.abs(got - want).max() <= 1e-4
     assert be.workspace_status() == 0
+
+
+def test_captured_call_replayed_on_other_data_keeps_its_number(be, dev):
+    """A captured call carries ITS number (the value its first pass flags a tile with) into every replay: a tile flagged in one replay
+    stays flagged in the next -- it is then read as floats, which is always right -- and a tile that stops being grey levels is flagged."""
+    sm, tmc = (t.to(dev) for t in _ref())      # (on the device: a capture admits no host-to-device copy)
+    clean = synth.as_dtype(synth.he_batch(16, 256, 256, seed0=5600), torch.float32).to(dev)
+    odd = clean.clone()
+    odd[3] = (odd[3] + 2e-4).clamp(0.0, 1.0)
+    odd[9, 1, 7, 7] = 0.4242
+    want_clean = be.transform(clean, sm, tmc, _extra_flags=CLASSIC | NO_CODES)
+    want_odd = be.transform(odd, sm, tmc, _extra_flags=CLASSIC | NO_CODES)
+    for form in (CLASSIC, TWO_PASS):
+        x = clean.clone()
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                be.transform(x, sm, tmc, _extra_flags=form)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = be.transform(x, sm, tmc, _extra_flags=form)
+        for data, want in ((clean, want_clean), (odd, want_odd), (clean, want_clean), (odd, want_odd)):
+            x.copy_(data)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want)
