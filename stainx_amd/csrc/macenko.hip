@@ -558,6 +558,7 @@ __device__ __forceinline__ void store_codes(const Geometry& g, const Workspace& 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         uint8_t* dst = ws.codes + ((size_t)tile * 3 + c) * g.pixels + p;
+        // (plain stores: the later passes find the codes in the L2s / the Infinity Cache -- non-temporal ones made pass A 54 -> 55.6 us and the reconstruct pass 37.4 -> 41.3)
         if constexpr (W == 1) *reinterpret_cast<uint32_t*>(dst) = word[c][0]; else *reinterpret_cast<uint2*>(dst) = make_uint2(word[c][0], word[c][1]);
     }
 }
