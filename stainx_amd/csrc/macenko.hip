@@ -3165,6 +3165,7 @@ static int fit_typed(const void* images, const Geometry& g0, const Workspace& ws
     g.vec = vec ? 1 : 0;
     g.vec_width = W;
     set_sampling(g);
+    if (!(vec && std::is_same<T, float>::value)) g.code_epoch = 0u;      // (the coded passes: planar float32 tiles in 16-byte packs)
     const T* in = static_cast<const T*>(images);
     return vec ? run_estimate<T, W>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream)
                : run_estimate<T, 1>(in, g, ws, 1, 0, nullptr, he_out, max_c_out, stream);
@@ -3601,7 +3602,13 @@ extern "C" int sx_macenko_fit(const void* images, int dtype, int64_t n, int64_t 
     if (rc != SX_OK) return rc;
     if (!he_out || !max_c_out) return fail(SX_ERR_BAD_ARG, "he_out / max_c_out pointer is null");
     Geometry g = make_geometry(n, h * w, 1);
-    const Workspace ws = carve(ws_ptr, n, g.pixels);
+    // (a float32 batch: the moments pass leaves the tiles' 8-bit codes, the two bracket passes read them -- as in the transform's four passes)
+    size_t codes_at = 0;
+    if (coded_call(dtype, n, g.pixels, 0u) && ws_bytes >= coded_workspace_bytes(n, g.pixels, 0)) {
+        g.code_epoch = next_code_epoch();
+        codes_at = macenko::workspace_bytes(n, g.pixels, kWsBase);
+    }
+    const Workspace ws = carve(ws_ptr, n, g.pixels, codes_at);
     hipStream_t stream = static_cast<hipStream_t>(stream_ptr);
     switch (dtype) {
         case SX_U8: return fit_typed<uint8_t>(images, g, ws, he_out, max_c_out, stream);
